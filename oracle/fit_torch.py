@@ -1,0 +1,184 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of the
+reference's world-space Adam fitting path in PyTorch (fp32, autograd).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module.
+
+Pinned by ``tests/golden/world_fit_*.npz``: fixtures produced by the reference's own
+``WorldSpaceFitter.fit_frame`` (imported from ``/root/reference`` by
+``oracle/gen_golden.py``) on seeded synthetic inputs; ``tests/test_oracle_fit.py``
+checks this restatement against them.
+
+Reference lines followed (paths relative to ``/root/reference/keypoints2body``):
+
+* ``gmof``                          core/losses.py:6-10
+* ``angle_prior``                   core/losses.py:13-21
+* ``body_fitting_loss_3d``          core/losses.py:24-67
+* ``MaxMixturePrior.__init__``      core/prior.py:98-176   (buffers)
+* ``merged_log_likelihood``         core/prior.py:182-195
+* ``WorldSpaceFitter.fit_frame``    core/fitters/world_space.py:93-323
+  (clone/detach 121-125, conf handling 161-164, iteration count 214, parameter
+  list 215-229, Adam loop 248-256, final forward 258-278)
+* ``guess_init_transl_from_root``   core/fitters/world_space.py:13-50
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+# Body-pose indices and signs of the elbow/knee bending prior (losses.py:16-19).
+ANGLE_IDX = (52, 55, 9, 12)
+ANGLE_SIGN = (1.0, -1.0, -1.0, -1.0)
+
+
+@dataclass
+class FitWeights:
+    """Loss weights; defaults = what the reference's world fitter actually uses
+    (losses.py:33-38 defaults, with joint/preserve weights injected from
+    core/config.py:34-35 through estimators/optimization.py:75-85)."""
+
+    sigma: float = 100.0
+    pose_prior_weight: float = 4.78 * 1.5
+    shape_prior_weight: float = 5.0
+    angle_prior_weight: float = 15.2
+    joint_loss_weight: float = 600.0
+    pose_preserve_weight: float = 5.0
+
+
+class GMMPrior:
+    """Buffers of the max-mixture prior, built the way prior.py:133-163 builds them."""
+
+    def __init__(self, means, covars, weights):
+        covs32 = np.asarray(covars).astype(np.float32)
+        self.means = torch.tensor(np.asarray(means).astype(np.float32))
+        # prior.py:150-151: inverse taken per component on the float32 covariances
+        self.precisions = torch.tensor(np.stack([np.linalg.inv(c) for c in covs32]).astype(np.float32))
+        # prior.py:156-163: constant term from the *un-cast* covariances
+        sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in np.asarray(covars)])
+        const = (2 * np.pi) ** (69 / 2.0)
+        nll = np.asarray(np.asarray(weights) / (const * (sqrdets / sqrdets.min())))
+        self.nll_weights = torch.tensor(nll, dtype=torch.float32).unsqueeze(0)
+
+    def per_component(self, pose: torch.Tensor) -> torch.Tensor:
+        """(B,69) -> (B,M) values 0.5 d^T P d - log(nll_w)  (prior.py:183-189)."""
+        diff = pose.unsqueeze(1) - self.means
+        pd = torch.einsum("mij,bmj->bmi", [self.precisions, diff])
+        quad = (pd * diff).sum(dim=-1)
+        return 0.5 * quad - torch.log(self.nll_weights)
+
+    def __call__(self, pose: torch.Tensor, betas=None) -> torch.Tensor:
+        vals, _ = torch.min(self.per_component(pose), dim=1)   # prior.py:194
+        return vals
+
+
+def gmof(x, sigma):
+    x2 = x ** 2
+    s2 = sigma ** 2
+    return (s2 * x2) / (s2 + x2)
+
+
+def frame_losses(body_pose, preserve_pose, betas, model_joints, j3d, prior: GMMPrior,
+                 conf, w: FitWeights, preserve_on: bool) -> torch.Tensor:
+    """Per-frame total loss (B,), term by term as losses.py:49-66."""
+    if conf.dim() == 1:
+        conf = conf.view(1, -1)
+    joint = (w.joint_loss_weight ** 2) * ((conf ** 2) * gmof(model_joints - j3d, w.sigma).sum(dim=-1)).sum(dim=-1)
+    pose_prior = (w.pose_prior_weight ** 2) * prior(body_pose, betas)
+    signs = torch.tensor(ANGLE_SIGN, device=body_pose.device)
+    angle = (w.angle_prior_weight ** 2) * (torch.exp(body_pose[:, list(ANGLE_IDX)] * signs) ** 2).sum(dim=-1)
+    shape = (w.shape_prior_weight ** 2) * (betas ** 2).sum(dim=-1)
+    wp = w.pose_preserve_weight if preserve_on else 0.0
+    preserve = (wp ** 2) * ((body_pose - preserve_pose) ** 2).sum(dim=-1)
+    return joint + pose_prior + angle + shape + preserve
+
+
+@dataclass
+class FitTrace:
+    """Optional per-iteration record (parameters *after* the step, loss *before* it)."""
+
+    iters: list = field(default_factory=list)
+    global_orient: list = field(default_factory=list)
+    body_pose: list = field(default_factory=list)
+    betas: list = field(default_factory=list)
+    transl: list = field(default_factory=list)
+    loss: list = field(default_factory=list)          # (B,) per recorded iteration
+
+
+@dataclass
+class FitOutput:
+    global_orient: torch.Tensor
+    body_pose: torch.Tensor
+    betas: torch.Tensor
+    transl: torch.Tensor
+    joints: torch.Tensor
+    vertices: torch.Tensor
+    loss: torch.Tensor            # (B,) loss of the last iteration, before its step
+    trace: Optional[FitTrace] = None
+
+
+def fit_world_adam(model, prior: GMMPrior, global_orient, body_pose, betas, transl, j3d,
+                   conf=None, *, num_iters: int, lr: float = 1e-2, seq_ind: int = 0,
+                   model_idx: Optional[Sequence[int]] = None, target_idx: Optional[Sequence[int]] = None,
+                   weights: Optional[FitWeights] = None, freeze_betas: bool = False,
+                   trace_iters: Sequence[int] = (), record_all_losses: bool = False) -> FitOutput:
+    """Adam branch of ``WorldSpaceFitter.fit_frame`` for a batch of B frames.
+
+    The loss is a sum over frames with no cross-frame term (losses.py:67) and Adam
+    is element-wise, so a batch is B independent fits; the per-frame losses are kept
+    apart here so a caller can sum them to the reference's scalar.
+    """
+    w = weights or FitWeights()
+    go = global_orient.clone().detach().requires_grad_(True)
+    bp = body_pose.clone().detach().requires_grad_(True)
+    be = betas.clone().detach()
+    be.requires_grad = not freeze_betas
+    tr = transl.clone().detach().requires_grad_(True)
+    preserve = bp.clone().detach()
+    K = j3d.shape[1]
+    if conf is None:
+        conf = torch.ones(K)
+    elif conf.dim() == 2:
+        conf = conf[0]                     # world_space.py:163-164 (row 0 only)
+    model_idx = list(range(K)) if model_idx is None else list(model_idx)
+    target_idx = list(range(K)) if target_idx is None else list(target_idx)
+
+    def per_frame():
+        out = model(global_orient=go, body_pose=bp, betas=be, transl=tr)
+        return frame_losses(bp, preserve, be, out.joints[:, model_idx, :], j3d[:, target_idx, :],
+                            prior, conf[target_idx], w, preserve_on=seq_ind > 0)
+
+    params = [go, bp, tr] + ([] if freeze_betas else [be])   # world_space.py:215-229
+    opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999))
+    trace = FitTrace() if (trace_iters or record_all_losses) else None
+    last = None
+    for it in range(1, num_iters + 1):
+        opt.zero_grad()
+        lf = per_frame()
+        lf.sum().backward()
+        opt.step()
+        last = lf.detach()
+        if trace is not None:
+            if record_all_losses:
+                trace.loss.append(last.clone())
+            if it in trace_iters:
+                trace.iters.append(it)
+                trace.global_orient.append(go.detach().clone())
+                trace.body_pose.append(bp.detach().clone())
+                trace.betas.append(be.detach().clone())
+                trace.transl.append(tr.detach().clone())
+                if not record_all_losses:
+                    trace.loss.append(last.clone())
+    with torch.no_grad():
+        out = model(global_orient=go, body_pose=bp, betas=be, transl=tr, return_full_pose=False)
+    return FitOutput(go.detach(), bp.detach(), be.detach(), tr.detach(),
+                     out.joints.detach(), out.vertices.detach(), last, trace)
+
+
+def guess_init_transl(model, pose_aa, betas, j3d, root_model: int = 0, root_target: int = 0):
+    """transl = target root - model root at the initial pose (world_space.py:34-50)."""
+    with torch.no_grad():
+        out = model(global_orient=pose_aa[:, :3], body_pose=pose_aa[:, 3:], betas=betas)
+    return (j3d[:, root_target, :] - out.joints[:, root_model, :]).detach()
