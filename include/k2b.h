@@ -1,0 +1,152 @@
+/*
+ * k2b.h — C ABI of the MI355X-native SMPLify-style fitting engine (libk2b.so).
+ *
+ * The reference (saifkhichi96/keypoints2body) is pure Python and has no FFI; these
+ * entry points are what a binding for its hot path would call, one per Python-level
+ * seam that SURVEY.md §8(b) names.  Each declaration cites the reference interface it
+ * replaces (paths relative to /root/reference/keypoints2body).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns K2B_OK (0) or a negative k2b_status; k2b_last_error()
+ *     returns a thread-local, human-readable message for the last failure;
+ *   - "dev" pointers are device (HBM) addresses, e.g. torch `tensor.data_ptr()` of a
+ *     contiguous float32 tensor on the HIP device; "host" pointers are host memory;
+ *   - all matrices are row-major (C order), float32 unless stated;
+ *   - launches are stream-ordered on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream); no call synchronises the device except *_create;
+ *   - buffers are caller-owned; inputs are never written; handles may be shared by
+ *     threads as long as concurrent calls use different streams AND different
+ *     workspaces (one workspace per handle: serialise calls on one handle).
+ */
+#ifndef K2B_H
+#define K2B_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum k2b_status {
+    K2B_OK = 0,
+    K2B_ERR_INVALID_ARGUMENT = -1, /* -> Python ValueError (world_space.py:118-119, adapters.py:104-117) */
+    K2B_ERR_UNSUPPORTED = -2,      /* -> Python NotImplementedError (api/frame.py:71-75) */
+    K2B_ERR_HIP = -3,              /* -> Python RuntimeError: a HIP runtime call failed */
+    K2B_ERR_NO_DEVICE = -4         /* -> Python RuntimeError: no gfx950 device / kernels not loadable */
+} k2b_status;
+
+typedef struct k2b_model k2b_model; /* body-model constants resident in HBM */
+typedef struct k2b_prior k2b_prior; /* max-mixture pose prior resident in HBM */
+
+/* Library / ABI version: (major << 16) | minor. */
+uint32_t k2b_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char *k2b_last_error(void);
+
+/* ---------------------------------------------------------------------------------
+ * Body model.  Replaces `load_body_model` / `smplx.create(...).to(device)`
+ * (api/model_factory.py:19-40) for the constants the path reads, and precomputes
+ * J_template = J_regressor . v_template and J_dirs = J_regressor . shapedirs (the
+ * dense J x V contraction, an fp32 MFMA kernel) so that the per-iteration kernel never
+ * touches vertices (SURVEY.md §8a note N1).
+ *
+ * All pointers are HOST pointers; the arrays are copied.
+ *   v_template  [V][3]        shapedirs [V][3][NB]      posedirs [9*(J-1)][3*V]
+ *   j_regressor [J][V]        lbs_weights [V][J]        parents [J] (parents[0] = -1,
+ *   extra_vertex_ids [E]      (output joints J..J+E-1 are these vertices)   parents[i] < i)
+ * Limits: 2 <= J <= 64, 1 <= NB <= 16, E >= 0.
+ * ------------------------------------------------------------------------------- */
+int k2b_model_create(k2b_model **out, int32_t num_vertices, int32_t num_joints, int32_t num_betas,
+                     int32_t num_extra_joints, const float *v_template, const float *shapedirs,
+                     const float *posedirs, const float *j_regressor, const float *lbs_weights,
+                     const int32_t *parents, const int32_t *extra_vertex_ids);
+void k2b_model_destroy(k2b_model *model);
+/* Sizes: V, J, NB, E. */
+int k2b_model_dims(const k2b_model *model, int32_t *num_vertices, int32_t *num_joints,
+                   int32_t *num_betas, int32_t *num_extra_joints);
+/* Copies the precomputed J_template [J][3] and J_dirs [J][3][NB] to HOST buffers (either may be NULL). */
+int k2b_model_joint_basis(const k2b_model *model, float *j_template, float *j_dirs);
+
+/* ---------------------------------------------------------------------------------
+ * Pose prior.  Replaces the buffers `MaxMixturePrior.__init__` registers
+ * (core/prior.py:133-163): `means [M][D]`, `precisions [M][D][D]`, `nll_weights [M]`
+ * (HOST pointers, float32, exactly those buffers).  D must equal 3*(J-1) of the model
+ * it is used with.  The library symmetrises each precision (0.5 (P + P^T), the exact
+ * gradient of the quadratic form) and stores -log(nll_weights).
+ * ------------------------------------------------------------------------------- */
+int k2b_prior_create(k2b_prior **out, int32_t num_gaussians, int32_t dim, const float *means,
+                     const float *precisions, const float *nll_weights);
+void k2b_prior_destroy(k2b_prior *prior);
+
+/* ---------------------------------------------------------------------------------
+ * Fit configuration.  Field-for-field the knobs of
+ *   WorldSpaceFitter.__init__/fit_frame   (core/fitters/world_space.py:56-66, 93-103, 214)
+ *   body_fitting_loss_3d                  (core/losses.py:24-38)
+ *   torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8)  (world_space.py:249)
+ * k2b_fit_config_default() fills the values the reference's world fitter uses.
+ * ------------------------------------------------------------------------------- */
+typedef struct k2b_fit_config {
+    int32_t num_iters;          /* num_iters_first if seq_ind == 0 else num_iters_followup */
+    double step_size;           /* Adam lr (config.py:30), 1e-2.  The four Adam numbers are doubles  */
+    double adam_beta1;          /* 0.9     because torch keeps them as Python floats and forms     */
+    double adam_beta2;          /* 0.999   1-beta, beta**t and lr/(1-beta1**t) in double before    */
+    double adam_eps;            /* 1e-8    rounding to float32 (torch/optim/adam.py)               */
+    float sigma;                /* GMoF sigma (losses.py:33), 100 */
+    float joint_loss_weight;    /* 600 (config.py:34) */
+    float pose_prior_weight;    /* 4.78*1.5 (losses.py:34) */
+    float angle_prior_weight;   /* 15.2 (losses.py:36) */
+    float shape_prior_weight;   /* 5.0 (losses.py:35) */
+    float pose_preserve_weight; /* 5.0 if seq_ind > 0 else 0 (world_space.py:211) */
+    int32_t freeze_betas;       /* betas excluded from the optimiser (world_space.py:171,228-229) */
+    int32_t conf_per_frame;     /* 0: conf is [K] shared by all frames (the reference's behaviour,
+                                   world_space.py:161-164); 1: conf is [B][K] */
+    int32_t angle_prior_index[4]; /* body-pose indices of the bending prior (losses.py:16): 52,55,9,12 */
+    float angle_prior_sign[4];    /* (losses.py:17): +1,-1,-1,-1 */
+} k2b_fit_config;
+
+void k2b_fit_config_default(k2b_fit_config *cfg);
+
+/* ---------------------------------------------------------------------------------
+ * k2b_fit_world — the hot path.  Replaces the Adam branch of
+ * `WorldSpaceFitter.fit_frame` (core/fitters/world_space.py:93-256) for a batch of B
+ * independent frames: per iteration the SMPL joint forward (Rodrigues, kinematic chain,
+ * J(beta)), `body_fitting_loss_3d` (core/losses.py:24-67) with `MaxMixturePrior`
+ * (core/prior.py:182-195), the analytic backward and the Adam update, all iterations
+ * fused in one launch (one frame per wavefront).
+ *
+ *   model_joint_index [K] HOST int32: model joint fitted to target k (the reference's
+ *       smpl_index / target_model_indices, world_space.py:194-201); values must be
+ *       distinct and < J (vertex-selected joints >= J: K2B_ERR_UNSUPPORTED).
+ *   j3d  dev [B][K][3]   target joints (already gathered with corr_index)
+ *   conf dev [K] or [B][K] (see conf_per_frame); NULL = ones
+ *   *_in dev: initial global_orient [B][3], body_pose [B][3(J-1)], betas [B][NB], transl [B][3]
+ *   preserve_pose dev [B][3(J-1)] or NULL (= body_pose_in, as world_space.py:159)
+ *   *_out dev: fitted parameters, same shapes (may alias the inputs)
+ *   loss_out dev [B]: per-frame loss of the LAST iteration evaluated BEFORE its step
+ *       (world_space.py:256); the reference's scalar is the sum over the batch
+ *   grad_out dev [B][P] or NULL: d loss / d params at the last iteration, P = 3J + NB + 3,
+ *       order [global_orient | body_pose | betas | transl] (debug / tests)
+ * ------------------------------------------------------------------------------- */
+int k2b_fit_world(const k2b_model *model, const k2b_prior *prior, const k2b_fit_config *cfg,
+                  int32_t num_frames, int32_t num_targets, const int32_t *model_joint_index,
+                  const float *j3d, const float *conf,
+                  const float *global_orient_in, const float *body_pose_in, const float *betas_in,
+                  const float *transl_in, const float *preserve_pose,
+                  float *global_orient_out, float *body_pose_out, float *betas_out, float *transl_out,
+                  float *loss_out, float *grad_out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * k2b_lbs — full SMPL forward.  Replaces `self.smpl(**kwargs)` (smplx `SMPL.forward`,
+ * call sites world_space.py:34,192,278; engine.py:114) for a batch:
+ *   joints_out dev [B][J+E][3], vertices_out dev [B][V][3] (NULL: joints only; the E
+ *   vertex-selected joints are then skinned alone).  transl may be NULL (no translation).
+ * ------------------------------------------------------------------------------- */
+int k2b_lbs(const k2b_model *model, int32_t num_frames, const float *global_orient,
+            const float *body_pose, const float *betas, const float *transl,
+            float *joints_out, float *vertices_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* K2B_H */

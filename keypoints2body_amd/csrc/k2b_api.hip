@@ -1,0 +1,428 @@
+// k2b_api.hip — the C ABI of libk2b.so (include/k2b.h): handles, host-side table
+// preparation, argument validation and kernel launches.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/k2b.h"
+#include "k2b_internal.h"
+
+namespace k2b {
+int skin_bpad(int num_frames);
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(K2B_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+hipError_t upload(T** dst, const T* src, size_t n) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), (n ? n : 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (n) e = hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace
+
+struct k2b_model {
+    int V = 0, J = 0, NB = 0, E = 0, P = 0;
+    float *v_template = nullptr, *shapedirs = nullptr, *posedirs = nullptr, *j_regressor = nullptr,
+          *lbs_weights = nullptr;
+    int *parents = nullptr, *extra_ids = nullptr;
+    float *j_template = nullptr, *j_dirs = nullptr;          // device
+    std::vector<float> h_j_template, h_j_dirs;               // host copies
+    // fused-fit tables (J == 24 only)
+    bool fit_ok = false;
+    std::string fit_why;
+    float *dt = nullptr, *dd = nullptr;
+    int* tree = nullptr;
+    int max_depth = 0;
+    // LBS workspace (grow-only)
+    float *wsA = nullptr, *wsF = nullptr;
+    int ws_bpad = 0;
+    // Adam coefficient tables, one per (iters, lr, b1, b2); never overwritten once built
+    std::map<std::tuple<int, double, double, double>, float2*> adam_tables;
+    std::mutex mu;
+};
+
+struct k2b_prior {
+    int M = 0, D = 0;
+    float *pa_image = nullptr, *pb = nullptr, *row_const = nullptr, *nlw = nullptr;
+};
+
+extern "C" {
+
+uint32_t k2b_version(void) { return (1u << 16) | 0u; }
+const char* k2b_last_error(void) { return g_err.c_str(); }
+
+void k2b_fit_config_default(k2b_fit_config* c) {
+    if (!c) return;
+    c->num_iters = 30;           // FrameOptimizeConfig.num_iters_first (core/config.py:32)
+    c->step_size = 1e-2;
+    c->adam_beta1 = 0.9;
+    c->adam_beta2 = 0.999;
+    c->adam_eps = 1e-8;
+    c->sigma = 100.0f;
+    c->joint_loss_weight = 600.0f;
+    c->pose_prior_weight = (float)(4.78 * 1.5);
+    c->angle_prior_weight = 15.2f;
+    c->shape_prior_weight = 5.0f;
+    c->pose_preserve_weight = 0.0f;
+    c->freeze_betas = 0;
+    c->conf_per_frame = 0;
+    const int idx[4] = {52, 55, 9, 12};
+    const float sg[4] = {1.f, -1.f, -1.f, -1.f};
+    for (int i = 0; i < 4; ++i) { c->angle_prior_index[i] = idx[i]; c->angle_prior_sign[i] = sg[i]; }
+}
+
+int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t E, const float* v_template,
+                     const float* shapedirs, const float* posedirs, const float* j_regressor,
+                     const float* lbs_weights, const int32_t* parents, const int32_t* extra_vertex_ids) {
+    if (!out) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: out is NULL");
+    *out = nullptr;
+    if (V <= 0 || J < 2 || J > k2b::kMaxJoints || NB < 1 || NB > k2b::kMaxBetas || E < 0)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: bad sizes V=%d J=%d NB=%d E=%d (need 2<=J<=64, 1<=NB<=16)", V, J, NB, E);
+    if (!v_template || !shapedirs || !posedirs || !j_regressor || !lbs_weights || !parents || (E > 0 && !extra_vertex_ids))
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: NULL constant array");
+    if (parents[0] >= 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: parents[0] must be -1 (root)");
+    for (int j = 1; j < J; ++j)
+        if (parents[j] < 0 || parents[j] >= j)
+            return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: parents[%d]=%d must be in [0,%d)", j, parents[j], j);
+    for (int e = 0; e < E; ++e)
+        if (extra_vertex_ids[e] < 0 || extra_vertex_ids[e] >= V)
+            return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: extra_vertex_ids[%d]=%d out of range", e, extra_vertex_ids[e]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(K2B_ERR_NO_DEVICE, "k2b_model_create: no HIP device visible (this engine has no CPU path)");
+
+    k2b_model* m = new k2b_model;
+    m->V = V; m->J = J; m->NB = NB; m->E = E; m->P = 9 * (J - 1);
+    HIP_TRY(upload(&m->v_template, v_template, (size_t)V * 3));
+    HIP_TRY(upload(&m->shapedirs, shapedirs, (size_t)V * 3 * NB));
+    HIP_TRY(upload(&m->posedirs, posedirs, (size_t)m->P * 3 * V));
+    HIP_TRY(upload(&m->j_regressor, j_regressor, (size_t)J * V));
+    HIP_TRY(upload(&m->lbs_weights, lbs_weights, (size_t)V * J));
+    HIP_TRY(upload(&m->parents, parents, (size_t)J));
+    HIP_TRY(upload(&m->extra_ids, extra_vertex_ids, (size_t)E));
+
+    // J x V contraction on the matrix cores
+    {
+        const int splits = 32;
+        const int Jp = (J + 15) / 16 * 16, Np = (3 * NB + 15) / 16 * 16;
+        float* ws = nullptr;
+        HIP_TRY(hipMalloc((void**)&ws, (size_t)splits * Jp * Np * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&m->j_template, (size_t)J * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&m->j_dirs, (size_t)J * 3 * NB * sizeof(float)));
+        HIP_TRY(k2b::launch_jreg_contract(m->j_regressor, m->v_template, m->j_template, J, V, 3, ws, splits, nullptr));
+        HIP_TRY(k2b::launch_jreg_contract(m->j_regressor, m->shapedirs, m->j_dirs, J, V, 3 * NB, ws, splits, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        m->h_j_template.resize((size_t)J * 3);
+        m->h_j_dirs.resize((size_t)J * 3 * NB);
+        HIP_TRY(hipMemcpy(m->h_j_template.data(), m->j_template, m->h_j_template.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(m->h_j_dirs.data(), m->j_dirs, m->h_j_dirs.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(ws));
+    }
+
+    // tables of the fused fit kernel
+    std::vector<int> depth(J, 0), nchild(J, 0);
+    std::vector<int> tree((size_t)J * 8, -1);
+    int maxd = 0;
+    bool ok = (J == k2b::kFitJoints);
+    if (!ok) m->fit_why = "the fused fit kernel is built for the 24-joint SMPL tree";
+    for (int j = 0; j < J; ++j) {
+        const int p = parents[j];
+        depth[j] = p < 0 ? 0 : depth[p] + 1;
+        maxd = depth[j] > maxd ? depth[j] : maxd;
+        tree[j * 8 + 0] = p;
+        tree[j * 8 + 1] = depth[j];
+        if (p >= 0) {
+            if (nchild[p] < 3) tree[p * 8 + 2 + nchild[p]] = j;
+            else if (ok) { ok = false; m->fit_why = "a joint has more than 3 children"; }
+            nchild[p]++;
+        }
+    }
+    m->max_depth = maxd;
+    std::vector<float> dt((size_t)J * 3), dd((size_t)J * 3 * k2b::kMaxBetas, 0.f);
+    for (int j = 0; j < J; ++j) {
+        const int p = parents[j];
+        for (int c = 0; c < 3; ++c) {
+            dt[j * 3 + c] = m->h_j_template[j * 3 + c] - (p >= 0 ? m->h_j_template[p * 3 + c] : 0.f);
+            for (int k = 0; k < NB; ++k)
+                dd[(j * 3 + c) * k2b::kMaxBetas + k] =
+                    m->h_j_dirs[(j * 3 + c) * NB + k] - (p >= 0 ? m->h_j_dirs[(p * 3 + c) * NB + k] : 0.f);
+        }
+    }
+    HIP_TRY(upload(&m->dt, dt.data(), dt.size()));
+    HIP_TRY(upload(&m->dd, dd.data(), dd.size()));
+    HIP_TRY(upload(&m->tree, tree.data(), tree.size()));
+    m->fit_ok = ok;
+    *out = m;
+    return K2B_OK;
+}
+
+void k2b_model_destroy(k2b_model* m) {
+    if (!m) return;
+    (void)hipDeviceSynchronize();
+    float* fl[] = {m->v_template, m->shapedirs, m->posedirs, m->j_regressor, m->lbs_weights, m->j_template,
+                   m->j_dirs, m->dt, m->dd, m->wsA, m->wsF};
+    for (float* p : fl) if (p) (void)hipFree(p);
+    if (m->parents) (void)hipFree(m->parents);
+    if (m->extra_ids) (void)hipFree(m->extra_ids);
+    if (m->tree) (void)hipFree(m->tree);
+    for (auto& kv : m->adam_tables) (void)hipFree(kv.second);
+    delete m;
+}
+
+int k2b_model_dims(const k2b_model* m, int32_t* V, int32_t* J, int32_t* NB, int32_t* E) {
+    if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_dims: model is NULL");
+    if (V) *V = m->V;
+    if (J) *J = m->J;
+    if (NB) *NB = m->NB;
+    if (E) *E = m->E;
+    return K2B_OK;
+}
+
+int k2b_model_joint_basis(const k2b_model* m, float* j_template, float* j_dirs) {
+    if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_joint_basis: model is NULL");
+    if (j_template) memcpy(j_template, m->h_j_template.data(), m->h_j_template.size() * sizeof(float));
+    if (j_dirs) memcpy(j_dirs, m->h_j_dirs.data(), m->h_j_dirs.size() * sizeof(float));
+    return K2B_OK;
+}
+
+int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, const float* precisions,
+                     const float* nll_weights) {
+    if (!out) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_prior_create: out is NULL");
+    *out = nullptr;
+    if (!means || !precisions || !nll_weights) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_prior_create: NULL array");
+    if (D != k2b::kPriorDim) return fail(K2B_ERR_UNSUPPORTED, "k2b_prior_create: dim=%d, the fit kernel is built for 69-D body poses", D);
+    if (M < 1 || M > k2b::kPriorMaxGauss)
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_prior_create: num_gaussians=%d, supported 1..%d", M, k2b::kPriorMaxGauss);
+    for (int m = 0; m < M; ++m)
+        if (!(nll_weights[m] > 0.f)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_prior_create: nll_weights[%d] must be > 0", m);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(K2B_ERR_NO_DEVICE, "k2b_prior_create: no HIP device visible (this engine has no CPU path)");
+
+    constexpr int MG = k2b::kPriorMaxGauss;
+    // symmetrised precisions and c_m = P_m mu_m, in double
+    std::vector<double> Ps((size_t)M * D * D), c((size_t)M * D, 0.0);
+    for (int m = 0; m < M; ++m)
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j)
+                Ps[((size_t)m * D + i) * D + j] =
+                    0.5 * ((double)precisions[((size_t)m * D + i) * D + j] + (double)precisions[((size_t)m * D + j) * D + i]);
+    for (int m = 0; m < M; ++m)
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s += Ps[((size_t)m * D + i) * D + j] * (double)means[m * D + j];
+            c[(size_t)m * D + i] = s;
+        }
+    auto P = [&](int m, int i, int j) -> float { return (float)Ps[((size_t)m * D + i) * D + j]; };
+
+    std::vector<float> pa((size_t)MG * (17 * 256 + 64), 0.f);
+    float* pa68 = pa.data() + (size_t)MG * 17 * 256;
+    std::vector<float> pb((size_t)MG * 9 * 64, 0.f), rc((size_t)2 * MG * 64 + 128, 0.f), nlw(MG, 0.f);
+    for (int m = 0; m < M; ++m) {
+        for (int l = 3; l < 64; ++l) {
+            const int i = l - 3;   // body-pose index of lane l (register set A)
+            for (int jb = 0; jb < 17; ++jb)
+                for (int e = 0; e < 4; ++e) pa[(((size_t)m * 17 + jb) * 64 + l) * 4 + e] = P(m, i, 4 * jb + e);
+            pa68[m * 64 + l] = P(m, i, 68);
+            rc[(0 * MG + m) * 64 + l] = means[m * D + i];
+            rc[(1 * MG + m) * 64 + l] = (float)c[(size_t)m * D + i];
+        }
+        for (int l = 0; l < 64; ++l) {
+            const int r = l & 7, s = l >> 3;
+            for (int cc = 0; cc < 9; ++cc) {
+                const int col = 9 * s + cc;
+                pb[((size_t)m * 9 + cc) * 64 + l] = col < D ? P(m, 61 + r, col) : 0.f;
+            }
+        }
+        nlw[m] = -logf(nll_weights[m]);
+    }
+    for (int l = 0; l < 64; ++l) {   // B rows after the butterfly: component s = l>>3, row 61 + (l&7)
+        const int r = l & 7, s = l >> 3;
+        if (s < M) {
+            rc[2 * MG * 64 + l] = means[s * D + 61 + r];
+            rc[2 * MG * 64 + 64 + l] = (float)c[(size_t)s * D + 61 + r];
+        }
+    }
+    k2b_prior* p = new k2b_prior;
+    p->M = M; p->D = D;
+    HIP_TRY(upload(&p->pa_image, pa.data(), pa.size()));
+    HIP_TRY(upload(&p->pb, pb.data(), pb.size()));
+    HIP_TRY(upload(&p->row_const, rc.data(), rc.size()));
+    HIP_TRY(upload(&p->nlw, nlw.data(), nlw.size()));
+    *out = p;
+    return K2B_OK;
+}
+
+void k2b_prior_destroy(k2b_prior* p) {
+    if (!p) return;
+    (void)hipDeviceSynchronize();
+    float* fl[] = {p->pa_image, p->pb, p->row_const, p->nlw};
+    for (float* q : fl) if (q) (void)hipFree(q);
+    delete p;
+}
+
+int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
+                  const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
+                  const float* bp_in, const float* be_in, const float* tr_in, const float* preserve, float* go_out,
+                  float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream) {
+    k2b_model* model = const_cast<k2b_model*>(model_c);
+    if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
+    if (!model->fit_ok) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: %s", model->fit_why.c_str());
+    if (prior->D != 3 * (model->J - 1)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: prior dim %d != 3*(J-1)", prior->D);
+    if (B < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_frames=%d", B);
+    if (K < 1 || K > model->J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_targets=%d out of range", K);
+    if (!model_joint_index) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index is NULL");
+    if (cfg->num_iters < 1 || cfg->num_iters > (1 << 20)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_iters=%d", cfg->num_iters);
+    if (!(cfg->step_size > 0.0) || !(cfg->adam_beta1 >= 0.0 && cfg->adam_beta1 < 1.0) || !(cfg->adam_beta2 >= 0.0 && cfg->adam_beta2 < 1.0))
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: bad Adam hyper-parameters");
+    if (B == 0) return K2B_OK;
+    if (!j3d || !go_in || !bp_in || !be_in || !tr_in || !go_out || !bp_out || !be_out || !tr_out)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: NULL parameter / target buffer (init transl is required, world_space.py:118-119)");
+
+    k2b::FitArgs a{};
+    int lane_target[k2b::kFitJoints];
+    for (int j = 0; j < k2b::kFitJoints; ++j) lane_target[j] = -1;
+    for (int k = 0; k < K; ++k) {
+        const int j = model_joint_index[k];
+        if (j < 0 || j >= model->J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index[%d]=%d out of range", k, j);
+        if (j >= model->J)
+            return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: model_joint_index[%d]=%d is a vertex-selected joint; the fused kernel fits kinematic joints only", k, j);
+        if (lane_target[j] >= 0) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: joint %d is targeted twice", j);
+        lane_target[j] = k;
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int ai = cfg->angle_prior_index[i];
+        if (ai < 0 || ai >= 61) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: angle_prior_index[%d]=%d must be in [0,61)", i, ai);
+        a.angle_index[i] = ai;
+        a.angle_sign[i] = cfg->angle_prior_sign[i];
+    }
+
+    // Adam bias terms in double, exactly as torch/optim/adam.py computes them in Python floats
+    float2* coef = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(model->mu);
+        const auto key = std::make_tuple((int)cfg->num_iters, cfg->step_size, cfg->adam_beta1, cfg->adam_beta2);
+        auto it = model->adam_tables.find(key);
+        if (it == model->adam_tables.end()) {
+            std::vector<float2> h(cfg->num_iters);
+            const double lr = cfg->step_size, b1 = cfg->adam_beta1, b2 = cfg->adam_beta2;
+            for (int t = 1; t <= cfg->num_iters; ++t) {
+                const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
+                h[t - 1] = make_float2((float)(lr / bc1), (float)std::sqrt(bc2));
+            }
+            HIP_TRY(upload(&coef, h.data(), h.size()));
+            model->adam_tables[key] = coef;
+        } else {
+            coef = it->second;
+        }
+    }
+
+    a.dt = model->dt; a.dd = model->dd; a.tree = model->tree;
+    a.max_depth = model->max_depth; a.num_betas = model->NB;
+    a.pa_image = prior->pa_image; a.pb = prior->pb; a.row_const = prior->row_const; a.neg_log_nllw = prior->nlw;
+    a.num_gauss = prior->M;
+    a.num_frames = B; a.num_targets = K;
+    memcpy(a.lane_target, lane_target, sizeof lane_target);
+    a.j3d = j3d; a.conf = conf; a.conf_per_frame = cfg->conf_per_frame ? 1 : 0;
+    a.go_in = go_in; a.bp_in = bp_in; a.be_in = be_in; a.tr_in = tr_in; a.preserve = preserve;
+    a.go_out = go_out; a.bp_out = bp_out; a.be_out = be_out; a.tr_out = tr_out;
+    a.loss_out = loss_out; a.grad_out = grad_out;
+    a.adam_coef = coef; a.num_iters = cfg->num_iters;
+    // 1 - beta is formed in double (Python float) and only then rounded to the tensor dtype
+    a.one_minus_beta1 = (float)(1.0 - cfg->adam_beta1);
+    a.beta2 = (float)cfg->adam_beta2; a.one_minus_beta2 = (float)(1.0 - cfg->adam_beta2);
+    a.eps = (float)cfg->adam_eps;
+    a.sigma = cfg->sigma; a.joint_w = cfg->joint_loss_weight; a.pose_prior_w = cfg->pose_prior_weight;
+    a.angle_w = cfg->angle_prior_weight; a.shape_w = cfg->shape_prior_weight; a.preserve_w = cfg->pose_preserve_weight;
+    a.freeze_betas = cfg->freeze_betas ? 1 : 0;
+    a.num_cus = device_cus();
+    HIP_TRY(k2b::launch_fit_world(a, (hipStream_t)stream));
+    return K2B_OK;
+}
+
+int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* bp, const float* be, const float* tr,
+            float* joints_out, float* vertices_out, void* stream_v) {
+    k2b_model* m = const_cast<k2b_model*>(model_c);
+    if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_lbs: model is NULL");
+    if (B < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_lbs: num_frames=%d", B);
+    if (B == 0) return K2B_OK;
+    if (!go || !bp || !be) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_lbs: NULL parameter buffer");
+    if (!joints_out && !vertices_out) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_lbs: no output requested");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int bpad = k2b::skin_bpad(B);
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (bpad > m->ws_bpad) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (m->wsA) HIP_TRY(hipFree(m->wsA));
+            if (m->wsF) HIP_TRY(hipFree(m->wsF));
+            m->wsA = m->wsF = nullptr;
+            m->ws_bpad = 0;
+            HIP_TRY(hipMalloc((void**)&m->wsA, (size_t)m->J * 12 * bpad * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&m->wsF, (size_t)m->P * bpad * sizeof(float)));
+            HIP_TRY(hipMemset(m->wsA, 0, (size_t)m->J * 12 * bpad * sizeof(float)));
+            HIP_TRY(hipMemset(m->wsF, 0, (size_t)m->P * bpad * sizeof(float)));
+            m->ws_bpad = bpad;
+        }
+    }
+    k2b::PoseArgs pa{};
+    pa.j_template = m->j_template; pa.j_dirs = m->j_dirs; pa.parents = m->parents;
+    pa.num_joints = m->J; pa.num_betas = m->NB; pa.num_out_joints = m->J + m->E; pa.num_frames = B;
+    pa.go = go; pa.bp = bp; pa.be = be; pa.tr = tr;
+    pa.A = m->wsA; pa.feat = m->wsF; pa.joints_out = joints_out;
+    k2b::SkinArgs sa{};
+    sa.num_vertices = m->V; sa.num_joints = m->J; sa.num_betas = m->NB; sa.num_pose_feats = m->P;
+    sa.v_template = m->v_template; sa.shapedirs = m->shapedirs; sa.posedirs = m->posedirs; sa.lbs_weights = m->lbs_weights;
+    sa.num_frames = B; sa.be = be; sa.tr = tr; sa.A = m->wsA; sa.feat = m->wsF;
+    HIP_TRY(k2b::launch_pose_setup(pa, stream));
+    if (vertices_out) {
+        sa.vertex_ids = nullptr; sa.num_out = m->V; sa.out = vertices_out; sa.out_stride = m->V; sa.out_row0 = 0;
+        HIP_TRY(k2b::launch_skin(sa, stream));
+    }
+    if (joints_out && m->E > 0) {
+        sa.vertex_ids = m->extra_ids; sa.num_out = m->E; sa.out = joints_out; sa.out_stride = m->J + m->E; sa.out_row0 = m->J;
+        HIP_TRY(k2b::launch_skin(sa, stream));
+    }
+    return K2B_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// Device-side helpers shared by the fit and LBS kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace k2b {
+
+constexpr int kWave = 64;
+
+struct Mat3 {
+    float m[9];  // row-major
+};
+struct Vec3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ Vec3 cross(Vec3 a, Vec3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Vec3 mul(const Mat3& A, Vec3 v) {
+    return {A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z,
+            A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z};
+}
+__device__ __forceinline__ Vec3 mulT(const Mat3& A, Vec3 v) {  // A^T v
+    return {A.m[0] * v.x + A.m[3] * v.y + A.m[6] * v.z, A.m[1] * v.x + A.m[4] * v.y + A.m[7] * v.z,
+            A.m[2] * v.x + A.m[5] * v.y + A.m[8] * v.z};
+}
+__device__ __forceinline__ Mat3 mul(const Mat3& A, const Mat3& B) {
+    Mat3 C;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            C.m[3 * r + c] = A.m[3 * r] * B.m[c] + A.m[3 * r + 1] * B.m[3 + c] + A.m[3 * r + 2] * B.m[6 + c];
+    return C;
+}
+
+// Wave-local ordering point for LDS traffic exchanged between lanes of ONE wave: DS
+// instructions of a wave execute in issue order, so only the compiler must be stopped
+// from moving a read above another lane's write.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float read_lane(float v, int lane) {  // lane must be wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Rodrigues' formula exactly as smplx.lbs.batch_rodrigues evaluates it
+// (oracle/smpl_torch.py::batch_rodrigues): angle = ||theta + 1e-8||, u = theta / angle,
+// R = I + sin(angle) K + (1 - cos(angle)) K K with K = skew(u).
+struct Rodrigues {
+    Mat3 R;
+    Vec3 u;
+    float angle, s, c;
+};
+
+__device__ __forceinline__ Rodrigues rodrigues_fwd(Vec3 th) {
+    Rodrigues o;
+    const float ex = th.x + 1e-8f, ey = th.y + 1e-8f, ez = th.z + 1e-8f;
+    o.angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    o.u = {th.x / o.angle, th.y / o.angle, th.z / o.angle};
+    o.s = sinf(o.angle);
+    o.c = cosf(o.angle);
+    const float omc = 1.0f - o.c;
+    const float ux = o.u.x, uy = o.u.y, uz = o.u.z;
+    // K K = u u^T - (u.u) I restricted to what the matrix product gives
+    const float xx = ux * ux, yy = uy * uy, zz = uz * uz, xy = ux * uy, xz = ux * uz, yz = uy * uz;
+    o.R.m[0] = 1.0f + omc * (-(yy + zz));
+    o.R.m[1] = o.s * (-uz) + omc * xy;
+    o.R.m[2] = o.s * uy + omc * xz;
+    o.R.m[3] = o.s * uz + omc * xy;
+    o.R.m[4] = 1.0f + omc * (-(xx + zz));
+    o.R.m[5] = o.s * (-ux) + omc * yz;
+    o.R.m[6] = o.s * (-uy) + omc * xz;
+    o.R.m[7] = o.s * ux + omc * yz;
+    o.R.m[8] = 1.0f + omc * (-(xx + yy));
+    return o;
+}
+
+// Reverse mode of rodrigues_fwd: G = dL/dR (row-major) -> dL/dtheta, following the same
+// elementary operations autograd differentiates (norm, divide, sin, cos, K, K K).
+__device__ __forceinline__ Vec3 rodrigues_bwd(const Rodrigues& f, Vec3 th, const Mat3& G) {
+    const float ux = f.u.x, uy = f.u.y, uz = f.u.z;
+    const float omc = 1.0f - f.c;
+    // <G, K>
+    const float g_s = ux * (G.m[7] - G.m[5]) + uy * (G.m[2] - G.m[6]) + uz * (G.m[3] - G.m[1]);
+    // <G, K K>
+    const float xx = ux * ux, yy = uy * uy, zz = uz * uz, xy = ux * uy, xz = ux * uz, yz = uy * uz;
+    const float g_omc = G.m[0] * (-(yy + zz)) + G.m[4] * (-(xx + zz)) + G.m[8] * (-(xx + yy)) +
+                        (G.m[1] + G.m[3]) * xy + (G.m[2] + G.m[6]) * xz + (G.m[5] + G.m[7]) * yz;
+    // H = dL/dK = s G + omc (G K^T + K^T G)
+    Mat3 K;
+    K.m[0] = 0.f; K.m[1] = -uz; K.m[2] = uy;
+    K.m[3] = uz;  K.m[4] = 0.f; K.m[5] = -ux;
+    K.m[6] = -uy; K.m[7] = ux;  K.m[8] = 0.f;
+    const Mat3 GK = mul(G, K), KG = mul(K, G);  // K^T = -K
+    Mat3 H;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H.m[i] = f.s * G.m[i] - omc * (GK.m[i] + KG.m[i]);
+    const Vec3 g_u = {H.m[7] - H.m[5], H.m[2] - H.m[6], H.m[3] - H.m[1]};
+    const float a = f.angle;
+    const float g_a = f.c * g_s + f.s * g_omc - (g_u.x * th.x + g_u.y * th.y + g_u.z * th.z) / (a * a);
+    return {g_u.x / a + g_a * (th.x + 1e-8f) / a, g_u.y / a + g_a * (th.y + 1e-8f) / a,
+            g_u.z / a + g_a * (th.z + 1e-8f) / a};
+}
+
+}  // namespace k2b
