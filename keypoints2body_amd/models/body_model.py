@@ -1,0 +1,106 @@
+"""Device-resident body model: the object behind the reference's ``model=`` hook.
+
+The reference obtains its body model from ``smplx.create(...)``
+(reference ``keypoints2body/api/model_factory.py:19-40``) and only ever calls it with
+smplx-style keyword arguments, reading ``.joints`` / ``.vertices`` from the result
+(``core/fitters/world_space.py:174-192,259-278``) plus a few optional attributes
+(``core/engine.py:140,146,155,180,194-195``).  ``BodyModel`` satisfies that duck
+type, but its forward is the HIP LBS kernel (``csrc/k2b_lbs.hip``) and its constant
+tensors live in HBM behind a ``k2b_model`` handle that the fused fit kernel shares.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import native, synthetic
+
+
+class BodyModel:
+    """SMPL-family model on one MI355X.  No CPU path: construction needs a HIP device."""
+
+    NUM_BODY_JOINTS = 23
+
+    def __init__(self, v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents,
+                 extra_vertex_ids=None, device=None, model_type: str = "smpl"):
+        self.native = native.NativeModel(v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents,
+                                         extra_vertex_ids, device=device)
+        self.device = self.native.device
+        self.model_type = model_type
+        self.num_betas = self.native.num_betas
+        self.num_joints = self.native.num_joints
+        self.num_vertices = self.native.num_vertices
+        self.parents = torch.as_tensor(np.asarray(parents), dtype=torch.long)
+
+    # -- constructors ---------------------------------------------------------------------
+    @classmethod
+    def synthetic(cls, seed: int = 0, device=None) -> "BodyModel":
+        """SMPL-shaped synthetic model (see ``keypoints2body_amd.synthetic``)."""
+        c = synthetic.make_body_model(seed)
+        return cls(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents,
+                   c.extra_vertex_ids, device=device)
+
+    @classmethod
+    def from_smplx(cls, model, device=None) -> "BodyModel":
+        """Take the constants of a loaded ``smplx`` SMPL module (or any object exposing
+        ``v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents`` and,
+        optionally, ``vertex_joint_selector.extra_joints_idxs``)."""
+        get = lambda name: getattr(model, name)
+        selector = getattr(model, "vertex_joint_selector", None)
+        extra = getattr(selector, "extra_joints_idxs", None) if selector is not None else None
+        if extra is None:
+            extra = getattr(model, "extra_vertex_ids", None)
+        nb = int(getattr(model, "num_betas", get("shapedirs").shape[2]))
+        shapedirs = get("shapedirs")[:, :, :nb]
+        return cls(get("v_template"), shapedirs, get("posedirs"), get("J_regressor"), get("lbs_weights"),
+                   get("parents"), extra, device=device)
+
+    @classmethod
+    def from_npz(cls, path: str, device=None) -> "BodyModel":
+        with np.load(path) as z:
+            extra = z["extra_vertex_ids"] if "extra_vertex_ids" in z else None
+            return cls(z["v_template"], z["shapedirs"], z["posedirs"], z["J_regressor"], z["lbs_weights"],
+                       z["parents"], extra, device=device)
+
+    # -- smplx-style forward --------------------------------------------------------------
+    def _as_dev(self, x, cols) -> torch.Tensor:
+        t = torch.as_tensor(x, dtype=torch.float32).detach()
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        if t.shape[-1] != cols:
+            raise ValueError(f"expected a (B,{cols}) tensor, got {tuple(t.shape)}")
+        return t.to(self.device).contiguous()
+
+    def __call__(self, global_orient=None, body_pose=None, betas=None, transl=None,
+                 return_full_pose: bool = False, return_verts: bool = True, **unused):
+        given = [x for x in (global_orient, body_pose, betas, transl) if x is not None]
+        B = max((int(torch.as_tensor(x).reshape(-1, torch.as_tensor(x).shape[-1]).shape[0]) for x in given), default=1)
+        D = 3 * (self.num_joints - 1)
+        zeros = lambda c: torch.zeros((B, c), dtype=torch.float32, device=self.device)
+        go = self._as_dev(global_orient, 3) if global_orient is not None else zeros(3)
+        bp = self._as_dev(body_pose, D) if body_pose is not None else zeros(D)
+        be = self._as_dev(betas, self.num_betas) if betas is not None else zeros(self.num_betas)
+        tr = self._as_dev(transl, 3) if transl is not None else None
+        go, bp, be = (t.expand(B, -1).contiguous() if t.shape[0] != B else t for t in (go, bp, be))
+        if tr is not None and tr.shape[0] != B:
+            tr = tr.expand(B, -1).contiguous()
+        joints, verts = self.native.lbs(go, bp, be, tr, want_vertices=return_verts)
+        return SimpleNamespace(vertices=verts, joints=joints, betas=be, global_orient=go, body_pose=bp,
+                               full_pose=torch.cat((go, bp), dim=1) if return_full_pose else None)
+
+    forward = __call__
+
+
+def as_body_model(model, device=None) -> BodyModel:
+    """Accept this engine's ``BodyModel`` or adopt an smplx-style module's constants."""
+    if isinstance(model, BodyModel):
+        return model
+    needed = ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "parents")
+    if all(hasattr(model, n) for n in needed):
+        return BodyModel.from_smplx(model, device=device)
+    raise ValueError(
+        "model must be a keypoints2body_amd BodyModel or an smplx-style module exposing "
+        + ", ".join(needed) + "; an opaque callable cannot be run by the HIP kernels")

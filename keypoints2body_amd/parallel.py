@@ -1,0 +1,85 @@
+"""Multi-GPU execution of the fitting path: frames of a sequence shard across the
+GPUs of one node, one process per GPU, no communication during the Adam iterations,
+ONE collective at the end.
+
+The reference has no distributed code at all; what shards is its frame loop
+(reference ``keypoints2body/api/sequence.py:214-281``) in the modes where frames are
+independent: per-frame fits as ``optimize_params_frame`` does them (``api/frame.py:213-219``,
+always ``seq_ind=0``) or a sequence with ``use_previous_frame_init=False``.
+
+Collective: a single all-gather of the packed fitted parameters (+ per-frame loss):
+``3J + NB + 3 + 1`` floats per frame (344 B for SMPL) — latency-bound on the fully
+connected xGMI mesh, so one direct ``all_gather_into_tensor`` (RCCL), never a ring
+pipeline of small buckets.  Vertices and joints stay sharded on the GPU that
+produced them.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+PARAM_KEYS = ("global_orient", "body_pose", "betas", "transl")
+
+
+def shard_bounds(num_frames: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [start, stop) of ceil(T / G) frames for `rank` (last ranks may be short or empty)."""
+    per = (num_frames + world_size - 1) // world_size
+    start = min(rank * per, num_frames)
+    return start, min(start + per, num_frames)
+
+
+def pack_outputs(out: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """(B, P+1) row per frame: [global_orient | body_pose | betas | transl | loss]."""
+    return torch.cat([out[k] for k in PARAM_KEYS] + [out["loss"].reshape(-1, 1)], dim=1).contiguous()
+
+
+def unpack_outputs(packed: torch.Tensor, num_betas: int, pose_dim: int) -> Dict[str, torch.Tensor]:
+    sizes = (3, pose_dim, num_betas, 3, 1)
+    go, bp, be, tr, loss = torch.split(packed, sizes, dim=1)
+    return {"global_orient": go.contiguous(), "body_pose": bp.contiguous(), "betas": be.contiguous(),
+            "transl": tr.contiguous(), "loss": loss.reshape(-1).contiguous()}
+
+
+def gather_fit_outputs(out: Dict[str, torch.Tensor], dist=None, pad_to: Optional[int] = None) -> torch.Tensor:
+    """All-gather the packed outputs of every rank: returns (world * rows, P+1) on every rank.
+
+    `dist` is the ``torch.distributed`` module (process group already initialised; backend
+    ``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests).  `pad_to` = common row count
+    when shards are uneven (rows beyond a rank's own frames are zero).
+    """
+    packed = pack_outputs(out)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return packed
+    rows = packed.shape[0] if pad_to is None else pad_to
+    if packed.shape[0] != rows:
+        padded = packed.new_zeros((rows, packed.shape[1]))
+        padded[: packed.shape[0]] = packed
+        packed = padded
+    world = dist.get_world_size()
+    gathered = packed.new_empty((world * rows, packed.shape[1]))
+    dist.all_gather_into_tensor(gathered, packed)
+    return gathered
+
+
+def fit_frames_sharded(fit_fn: Callable[[slice], Dict[str, torch.Tensor]], num_frames: int, num_betas: int,
+                       pose_dim: int, dist=None) -> Dict[str, torch.Tensor]:
+    """Fit `num_frames` independent frames across all ranks and return the concatenated
+    parameters (+ per-frame loss) of the whole sequence on every rank.
+
+    `fit_fn(frame_slice)` fits this rank's block and returns the usual dict of (b, .)
+    tensors; on the GPUs it wraps ``WorldSpaceFitter.fit_batch``.  Frame order is preserved.
+    """
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    start, stop = shard_bounds(num_frames, world, rank)
+    per = (num_frames + world - 1) // world
+    out = fit_fn(slice(start, stop))
+    gathered = gather_fit_outputs(out, dist if world > 1 else None, pad_to=per)
+    if world > 1:
+        # drop the padding rows of short / empty trailing shards
+        keep = torch.cat([torch.arange(r * per, r * per + (shard_bounds(num_frames, world, r)[1]
+                                                            - shard_bounds(num_frames, world, r)[0]))
+                          for r in range(world)]).to(gathered.device)
+        gathered = gathered.index_select(0, keep)
+    return unpack_outputs(gathered, num_betas, pose_dim)
