@@ -106,6 +106,8 @@ typedef struct k2b_fit_config {
 } k2b_fit_config;
 
 void k2b_fit_config_default(k2b_fit_config *cfg);
+/* sizeof(k2b_fit_config) as compiled into the library: lets a binding verify its struct mirror. */
+uint32_t k2b_fit_config_size(void);
 
 /* ---------------------------------------------------------------------------------
  * k2b_fit_world — the hot path.  Replaces the Adam branch of

@@ -90,6 +90,8 @@ extern "C" {
 uint32_t k2b_version(void) { return (1u << 16) | 0u; }
 const char* k2b_last_error(void) { return g_err.c_str(); }
 
+uint32_t k2b_fit_config_size(void) { return (uint32_t)sizeof(k2b_fit_config); }
+
 void k2b_fit_config_default(k2b_fit_config* c) {
     if (!c) return;
     c->num_iters = 30;           // FrameOptimizeConfig.num_iters_first (core/config.py:32)

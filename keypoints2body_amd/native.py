@@ -25,7 +25,7 @@ K2B_ERR_NO_DEVICE = -4
 
 EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
-    "k2b_model_joint_basis", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default",
+    "k2b_model_joint_basis", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
     "k2b_fit_world", "k2b_lbs",
 )
 
@@ -86,6 +86,9 @@ def load_library():
     lib.k2b_prior_destroy.argtypes = [vp]
     lib.k2b_fit_config_default.restype = None
     lib.k2b_fit_config_default.argtypes = [C.POINTER(FitConfigC)]
+    lib.k2b_fit_config_size.restype = C.c_uint32
+    if lib.k2b_fit_config_size() != C.sizeof(FitConfigC):
+        raise RuntimeError("libk2b.so was built with a different k2b_fit_config layout than native.FitConfigC")
     lib.k2b_fit_world.restype = C.c_int
     lib.k2b_fit_world.argtypes = [vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 13 + [vp]
     lib.k2b_lbs.restype = C.c_int

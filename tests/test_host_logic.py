@@ -1,0 +1,80 @@
+"""Host-side logic that runs without a GPU: prior preparation, C-ABI surface, config
+conversion, loud failure when there is no device."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from keypoints2body_amd import native
+from keypoints2body_amd.core import config as cfgmod
+from keypoints2body_amd.prior import MixtureBuffers
+from tests import helpers as H
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def test_mixture_buffers_match_reference_derivation():
+    g = H.gmm_fixture()
+    b = MixtureBuffers.from_mixture(g["means"], g["covars"].astype(np.float64), g["weights"])
+    assert np.array_equal(b.means, g["ref_means"])
+    assert np.abs(b.precisions - g["ref_precisions"]).max() <= 1e-4 * np.abs(g["ref_precisions"]).max()
+    np.testing.assert_allclose(b.nll_weights, g["ref_nll_weights"].reshape(-1), rtol=1e-5)
+    with pytest.raises(ValueError):
+        MixtureBuffers.from_mixture(g["means"], g["covars"][:, :5], g["weights"])
+
+
+def test_missing_prior_file_exits_like_reference():
+    with pytest.raises(SystemExit):          # reference core/prior.py:126-131 calls sys.exit(-1)
+        MixtureBuffers.from_file("/nonexistent/gmm_08.pkl")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = (REPO / "include" / "k2b.h").read_text()
+    declared = set(re.findall(r"\b(k2b_[a-z_]+)\s*\(", header))
+    assert declared == set(native.EXPORTED_SYMBOLS)
+    lib = native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.k2b_version() >> 16 == 1
+
+
+def test_default_fit_config_carries_reference_weights():
+    c = native.default_fit_config()
+    assert (c.num_iters, c.step_size, c.adam_beta1, c.adam_beta2, c.adam_eps) == (30, 1e-2, 0.9, 0.999, 1e-8)
+    assert c.sigma == 100.0 and c.joint_loss_weight == 600.0 and c.shape_prior_weight == 5.0
+    assert abs(c.pose_prior_weight - 4.78 * 1.5) < 1e-6 and abs(c.angle_prior_weight - 15.2) < 1e-6
+    assert list(c.angle_prior_index) == [52, 55, 9, 12] and list(c.angle_prior_sign) == [1.0, -1.0, -1.0, -1.0]
+    assert ctypes.sizeof(native.FitConfigC) == native.load_library().k2b_fit_config_size()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device failure mode")
+def test_no_device_fails_loudly_not_silently():
+    c = H.body_consts()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        native.NativeModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents,
+                           c.extra_vertex_ids)
+    # straight through the C ABI: k2b_model_create must report K2B_ERR_NO_DEVICE, not compute on the host
+    lib = native.load_library()
+    h = ctypes.c_void_p()
+    f32 = lambda a: np.ascontiguousarray(a, np.float32).ctypes.data_as(ctypes.c_void_p)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data_as(ctypes.c_void_p)
+    rc = lib.k2b_model_create(ctypes.byref(h), 6890, 24, 10, 21, f32(c.v_template), f32(c.shapedirs), f32(c.posedirs),
+                              f32(c.J_regressor), f32(c.lbs_weights), i32(c.parents), i32(c.extra_vertex_ids))
+    assert rc == native.K2B_ERR_NO_DEVICE and b"no HIP device" in lib.k2b_last_error()
+    bad = np.array(c.parents, np.int32); bad[5] = 9
+    rc = lib.k2b_model_create(ctypes.byref(h), 6890, 24, 10, 21, f32(c.v_template), f32(c.shapedirs), f32(c.posedirs),
+                              f32(c.J_regressor), f32(c.lbs_weights), i32(bad), i32(c.extra_vertex_ids))
+    assert rc == native.K2B_ERR_INVALID_ARGUMENT
+
+
+def test_config_conversion_matches_reference_rules():
+    f = cfgmod.frame_config_from({"use_lbfgs": False, "num_iters_first": 100})
+    assert f.use_lbfgs is False and f.num_iters_first == 100 and f.joint_loss_weight == 600.0
+    s = cfgmod.sequence_config_from({"frame": {"use_lbfgs": False}, "use_shape_optimization": False, "fix_foot": True})
+    assert s.frame.use_lbfgs is False and s.use_shape_optimization is False and s.fix_foot and s.num_shape_frames == 50
+    assert cfgmod.sequence_config_from(None).frame.joints_category == "AMASS"
+    with pytest.raises(TypeError):
+        cfgmod.frame_config_from({"no_such_field": 1})

@@ -1,0 +1,55 @@
+"""Pins the oracle (oracle/fit_torch.py) to the golden vectors produced by the REAL
+reference fitter (oracle/gen_golden.py, run in the build container)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.fit_torch import fit_world_adam
+from tests import helpers as H
+
+TOL = 2e-6   # same arithmetic, same library: differences are batch-shape / thread effects only
+
+
+def test_prior_known_answers():
+    d = np.load(H.GOLDEN / "prior_probe.npz")
+    got = H.oracle_prior()(torch.tensor(d["pose"]), None).numpy()
+    np.testing.assert_allclose(got, d["value"], rtol=2e-6)
+
+
+def test_prior_buffers_rebuilt_from_mixture_match_reference():
+    from oracle.fit_torch import GMMPrior
+    g = H.gmm_fixture()
+    p = GMMPrior(g["means"], g["covars"].astype(np.float64), g["weights"])
+    assert np.abs(p.precisions.numpy() - g["ref_precisions"]).max() <= 1e-4 * np.abs(g["ref_precisions"]).max()
+    np.testing.assert_allclose(p.nll_weights.numpy(), g["ref_nll_weights"], rtol=1e-5)   # covars stored as f32
+
+
+@pytest.mark.parametrize("case", H.WORLD_CASES + ("generic_vertex_joints",))
+def test_oracle_reproduces_reference_fit(case):
+    d = H.load_case(case)
+    t = lambda k: torch.tensor(d[k])
+    idx = H.case_indices(d)
+    conf = t("conf") if int(d["has_conf"]) else None
+    out = fit_world_adam(H.oracle_model(), H.oracle_prior(), t("init_global_orient"), t("init_body_pose"),
+                         t("init_betas"), t("init_transl"), t("j3d"), conf, num_iters=int(d["num_iters"]),
+                         seq_ind=int(d["seq_ind"]), model_idx=idx, freeze_betas=bool(int(d["freeze_betas"])),
+                         trace_iters=tuple(int(i) for i in d["trace_iters"]), record_all_losses=True)
+    for ti in range(len(d["trace_iters"])):
+        assert np.abs(out.trace.global_orient[ti].numpy() - d["trace_global_orient"][ti]).max() < TOL
+        assert np.abs(out.trace.body_pose[ti].numpy() - d["trace_body_pose"][ti]).max() < TOL
+        assert np.abs(out.trace.betas[ti].numpy() - d["trace_betas"][ti]).max() < TOL
+        assert np.abs(out.trace.transl[ti].numpy() - d["trace_transl"][ti]).max() < TOL
+    for k, o in (("global_orient", out.global_orient), ("body_pose", out.body_pose), ("betas", out.betas),
+                 ("transl", out.transl), ("joints", out.joints)):
+        assert np.abs(o.numpy() - d["out_" + k]).max() < TOL
+    vid = torch.as_tensor(d["sampled_vertex_ids"])
+    assert np.abs(out.vertices[:, vid].numpy() - d["out_verts_sampled"]).max() < TOL
+    # per-iteration losses the reference back-propagated (per call: sum over the call's batch)
+    mine = torch.stack(out.trace.loss, dim=0).double().numpy()          # (iters, B)
+    ref = d["iter_losses"]                                               # (calls, iters)
+    if int(d["per_frame_calls"]):
+        np.testing.assert_allclose(mine.T, ref, rtol=1e-5)
+    else:
+        np.testing.assert_allclose(mine.sum(axis=1)[None], ref, rtol=1e-5)
+    if int(d["freeze_betas"]):
+        assert np.array_equal(out.betas.numpy(), d["init_betas"])
