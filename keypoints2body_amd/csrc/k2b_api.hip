@@ -71,7 +71,7 @@ struct k2b_model {
     std::string fit_why;
     float *dt = nullptr, *dd = nullptr;
     int* tree = nullptr;
-    int max_depth = 0;
+    int num_rounds = 0, num_win_bits = 0;
     // LBS workspace (grow-only)
     float *wsA = nullptr, *wsF = nullptr;
     int ws_bpad = 0;
@@ -82,7 +82,7 @@ struct k2b_model {
 
 struct k2b_prior {
     int M = 0, D = 0;
-    float *pa_image = nullptr, *pb = nullptr, *row_const = nullptr, *nlw = nullptr;
+    float *pa_image = nullptr, *row_const = nullptr, *nlw = nullptr;
 };
 
 extern "C" {
@@ -160,38 +160,68 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         HIP_TRY(hipFree(ws));
     }
 
-    // tables of the fused fit kernel
-    std::vector<int> depth(J, 0), nchild(J, 0);
-    std::vector<int> tree((size_t)J * 8, -1);
-    int maxd = 0;
+    // tables of the fused fit kernel: lanes follow the DFS pre-order of the tree, so that every
+    // subtree is a contiguous lane range
     bool ok = (J == k2b::kFitJoints);
     if (!ok) m->fit_why = "the fused fit kernel is built for the 24-joint SMPL tree";
-    for (int j = 0; j < J; ++j) {
-        const int p = parents[j];
-        depth[j] = p < 0 ? 0 : depth[p] + 1;
+    std::vector<std::vector<int>> children(J);
+    std::vector<int> depth(J, 0);
+    int maxd = 0;
+    for (int j = 1; j < J; ++j) {
+        children[parents[j]].push_back(j);
+        depth[j] = depth[parents[j]] + 1;
         maxd = depth[j] > maxd ? depth[j] : maxd;
-        tree[j * 8 + 0] = p;
-        tree[j * 8 + 1] = depth[j];
-        if (p >= 0) {
-            if (nchild[p] < 3) tree[p * 8 + 2 + nchild[p]] = j;
-            else if (ok) { ok = false; m->fit_why = "a joint has more than 3 children"; }
-            nchild[p]++;
-        }
     }
-    m->max_depth = maxd;
-    std::vector<float> dt((size_t)J * 3), dd((size_t)J * 3 * k2b::kMaxBetas, 0.f);
-    for (int j = 0; j < J; ++j) {
-        const int p = parents[j];
-        for (int c = 0; c < 3; ++c) {
-            dt[j * 3 + c] = m->h_j_template[j * 3 + c] - (p >= 0 ? m->h_j_template[p * 3 + c] : 0.f);
-            for (int k = 0; k < NB; ++k)
-                dd[(j * 3 + c) * k2b::kMaxBetas + k] =
-                    m->h_j_dirs[(j * 3 + c) * NB + k] - (p >= 0 ? m->h_j_dirs[(p * 3 + c) * NB + k] : 0.f);
+    std::vector<int> order, lane_of(J, -1), size(J, 1);
+    {
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+            const int j = stack.back();
+            stack.pop_back();
+            lane_of[j] = (int)order.size();
+            order.push_back(j);
+            for (auto it = children[j].rbegin(); it != children[j].rend(); ++it) stack.push_back(*it);
+        }
+        for (int j = J - 1; j >= 1; --j) size[parents[j]] += size[j];
+    }
+    int rounds = 0, bits = 0;
+    while ((1 << rounds) < maxd + 1) ++rounds;
+    while ((1 << bits) <= J) ++bits;
+    if (ok && (rounds > k2b::kMaxRounds || bits > k2b::kMaxWinBits)) { ok = false; m->fit_why = "tree too deep / large for the fused fit kernel"; }
+    m->num_rounds = rounds;
+    m->num_win_bits = bits;
+    std::vector<int> tab((size_t)64 * k2b::kLaneTabStride, -1);
+    std::vector<float> dt((size_t)64 * 3, 0.f), dd((size_t)64 * 3 * k2b::kMaxBetas, 0.f);
+    if (ok) {
+        for (int l = 0; l < J; ++l) {
+            const int j = order[l], p = parents[j];
+            int* t = tab.data() + (size_t)l * k2b::kLaneTabStride;
+            t[0] = j;
+            t[1] = p >= 0 ? lane_of[p] : -1;
+            // ancestor lane 2^r levels up (pointer doubling), -1 once past the root
+            int anc = t[1];
+            for (int r = 0; r < k2b::kMaxRounds; ++r) {
+                t[2 + r] = anc;
+                for (int s = 0; s < (1 << r) && anc >= 0; ++s) {   // advance 2^r more levels
+                    const int aj = order[anc];
+                    anc = parents[aj] >= 0 ? lane_of[parents[aj]] : -1;
+                }
+            }
+            // subtree [l, l + size) as power-of-two windows, largest first
+            int off = 0;
+            for (int b = k2b::kMaxWinBits - 1; b >= 0; --b)
+                if (size[j] & (1 << b)) { t[2 + k2b::kMaxRounds + b] = l + off; off += 1 << b; }
+            for (int c = 0; c < 3; ++c) {
+                dt[l * 3 + c] = m->h_j_template[j * 3 + c] - (p >= 0 ? m->h_j_template[p * 3 + c] : 0.f);
+                for (int k = 0; k < NB; ++k)
+                    dd[(l * 3 + c) * k2b::kMaxBetas + k] =
+                        m->h_j_dirs[(j * 3 + c) * NB + k] - (p >= 0 ? m->h_j_dirs[(p * 3 + c) * NB + k] : 0.f);
+            }
         }
     }
     HIP_TRY(upload(&m->dt, dt.data(), dt.size()));
     HIP_TRY(upload(&m->dd, dd.data(), dd.size()));
-    HIP_TRY(upload(&m->tree, tree.data(), tree.size()));
+    HIP_TRY(upload(&m->tree, tab.data(), tab.size()));
     m->fit_ok = ok;
     *out = m;
     return K2B_OK;
@@ -256,9 +286,10 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
         }
     auto P = [&](int m, int i, int j) -> float { return (float)Ps[((size_t)m * D + i) * D + j]; };
 
-    std::vector<float> pa((size_t)MG * (17 * 256 + 64), 0.f);
+    std::vector<float> pa((size_t)k2b::kPriorImageFloats, 0.f);
     float* pa68 = pa.data() + (size_t)MG * 17 * 256;
-    std::vector<float> pb((size_t)MG * 9 * 64, 0.f), rc((size_t)2 * MG * 64 + 128, 0.f), nlw(MG, 0.f);
+    float* pb = pa.data() + (size_t)MG * (17 * 256 + 64);
+    std::vector<float> rc((size_t)2 * MG * 64 + 128, 0.f), nlw(MG, 0.f);
     for (int m = 0; m < M; ++m) {
         for (int l = 3; l < 64; ++l) {
             const int i = l - 3;   // body-pose index of lane l (register set A)
@@ -287,7 +318,6 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
     k2b_prior* p = new k2b_prior;
     p->M = M; p->D = D;
     HIP_TRY(upload(&p->pa_image, pa.data(), pa.size()));
-    HIP_TRY(upload(&p->pb, pb.data(), pb.size()));
     HIP_TRY(upload(&p->row_const, rc.data(), rc.size()));
     HIP_TRY(upload(&p->nlw, nlw.data(), nlw.size()));
     *out = p;
@@ -297,7 +327,7 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
 void k2b_prior_destroy(k2b_prior* p) {
     if (!p) return;
     (void)hipDeviceSynchronize();
-    float* fl[] = {p->pa_image, p->pb, p->row_const, p->nlw};
+    float* fl[] = {p->pa_image, p->row_const, p->nlw};
     for (float* q : fl) if (q) (void)hipFree(q);
     delete p;
 }
@@ -358,9 +388,9 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
         }
     }
 
-    a.dt = model->dt; a.dd = model->dd; a.tree = model->tree;
-    a.max_depth = model->max_depth; a.num_betas = model->NB;
-    a.pa_image = prior->pa_image; a.pb = prior->pb; a.row_const = prior->row_const; a.neg_log_nllw = prior->nlw;
+    a.dt = model->dt; a.dd = model->dd; a.lane_tab = model->tree;
+    a.num_rounds = model->num_rounds; a.num_win_bits = model->num_win_bits; a.num_betas = model->NB;
+    a.pa_image = prior->pa_image; a.row_const = prior->row_const; a.neg_log_nllw = prior->nlw;
     a.num_gauss = prior->M;
     a.num_frames = B; a.num_targets = K;
     memcpy(a.lane_target, lane_target, sizeof lane_target);

@@ -3,7 +3,7 @@
 // One launch runs ALL Adam iterations of `WorldSpaceFitter.fit_frame`'s Adam branch
 // (reference keypoints2body/core/fitters/world_space.py:248-256) for a batch of independent
 // frames.  One frame per 64-lane wavefront; a workgroup of up to 8 waves shares the GMM
-// precision matrices, which stay resident in LDS (141 KB of the CU's 160 KB) for the whole
+// precision matrices, which stay resident in LDS (156 KB of the CU's 160 KB) for the whole
 // launch.  Per iteration and frame nothing is read from or written to HBM.
 //
 // Lane roles of a wave
@@ -11,11 +11,19 @@
 //                  and p = 64 + l (set B); p runs over [global_orient 3 | body_pose 69 |
 //                  betas NB | transl 3].  The GMM rows use this layout too: lane l <-> body
 //                  pose index l-3 (set A), lanes 0..7 of set B <-> indices 61..68.
-//   "joint layout" lane j < 24 owns joint j of the kinematic tree: Rodrigues, the chain
-//                  down-sweep (parent records staged in wave-private LDS), the loss
-//                  gradient, the up-sweep of subtree force/torque sums and the Rodrigues
-//                  reverse mode.
+//   "tree layout"  lane t < 24 owns the t-th joint of the kinematic tree in DFS pre-order, so
+//                  every subtree is a contiguous lane range.  Global transforms come from a
+//                  pointer-doubling down-sweep (log2(depth) rounds of cross-lane moves instead
+//                  of one round per level); subtree force / torque sums come from windowed
+//                  sums over lane ranges (no level loop, no cancellation).  All tree traffic is
+//                  ds_bpermute cross-lane moves: the "tree in LDS" is the LDS crossbar, with no
+//                  LDS allocation.
 // The two layouts exchange values through a 96-float wave-private LDS staging strip.
+//
+// Latency, not throughput, bounds this kernel at one wave per SIMD (1024 frames on 1024
+// SIMDs), so every phase is written to keep many independent LDS operations in flight:
+// the GMM matrix-vector products are software-pipelined by hand (sched_barrier pins the
+// order: next block's 9 ds_read_b128 are issued before the current block's 32 FMAs).
 //
 // Arithmetic restated (see oracle/fit_torch.py for the CPU twin and the reference lines):
 //   joints  p_j = p_par + Rg_par (J_j(beta) - J_par(beta)),  Rg_j = Rg_par R_j   (smplx chain)
@@ -26,18 +34,42 @@
 
 namespace k2b {
 
+// Diagnostic build only (-DK2B_FIT_STAMPS, tools/stamp_build.sh): s_memtime stamps of one
+// iteration of wave 0 / block 0, written to a buffer no other code reads.  The shipped
+// library is built without it: no stamp executes there.
+#ifdef K2B_FIT_STAMPS
+__device__ unsigned long long* g_k2b_stamps = nullptr;
+#define K2B_STAMP(i)                                                                         \
+    do {                                                                                     \
+        if (stamp_on) {                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            unsigned long long t__;                                                          \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            if (lane == 0) g_k2b_stamps[i] = t__;                                            \
+        }                                                                                    \
+    } while (0)
+#else
+#define K2B_STAMP(i)
+#endif
+
 namespace {
 
-constexpr int NJ = kFitJoints;          // 24
+static_assert(kFitJoints == 24, "lane tables are built for the SMPL tree");
 constexpr int D = kPriorDim;            // 69
 constexpr int MAXW = kFitMaxWaves;      // waves (frames) per workgroup
-constexpr int PA_FLOATS = kPriorMaxGauss * (17 * 256 + 64);  // 35328
+constexpr int MG = kPriorMaxGauss;      // 8
+constexpr int PA_FLOATS = MG * (17 * 256 + 64);   // rows 0..60 (lanes 3..63): [m][17][64][4] + [m][64]
+constexpr int PB_FLOATS = MG * 9 * 64;            // rows 61..68: [m][9][64]
+constexpr int P_FLOATS = PA_FLOATS + PB_FLOATS;   // 39936 floats = 159744 B
 constexpr int XS = 96;                  // staging strip: go@0, body@4, betas@76, transl@92
 constexpr int XS_BODY = 4, XS_BETA = 76, XS_TRANSL = 92;
-constexpr int TREE_REC = 16;            // Rg(9) p(3) pad(4)
-constexpr int UP_REC = 8;               // a(3) tau(3) pad(2)
-constexpr int WAVE_LDS = XS + NJ * TREE_REC + NJ * UP_REC;  // 672 floats
-static_assert((PA_FLOATS + MAXW * WAVE_LDS) * 4 <= 163840, "LDS budget");
+static_assert(P_FLOATS == kPriorImageFloats, "host image size");
+static_assert((P_FLOATS + MAXW * XS) * 4 <= 163840, "LDS budget");
+
+__device__ __forceinline__ float bperm(int byte_addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
 
 // 8 per-lane values -> one value per lane: lane l ends with the sum over the 8 lanes
 // {l&7 + 8 s} of v[(l>>3)&7].  7 cross-lane moves instead of 24.
@@ -93,8 +125,9 @@ __device__ __forceinline__ float butterfly16_sum(const float (&v)[16], int lane)
 
 }  // namespace
 
+template <int NBT>
 __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[PA_FLOATS + MAXW * WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) float lds[P_FLOATS + MAXW * XS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,18 +139,17 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     {
         const float4* src = reinterpret_cast<const float4*>(a.pa_image);
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = tid; i < PA_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = tid; i < P_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
 
     const int f = blockIdx.x * waves + wave;   // frame of this wave
     if (f >= a.num_frames) return;             // no further workgroup-wide sync below
 
-    float* xs = lds + PA_FLOATS + wave * WAVE_LDS;
-    float* tree = xs + XS;
-    float* up = tree + NJ * TREE_REC;
-    const float* pa = lds;                                    // [m][17][64][4]
-    const float* pa68 = lds + kPriorMaxGauss * 17 * 256;      // [m][64]
+    float* xs = lds + P_FLOATS + wave * XS;
+    const float4* pa4 = reinterpret_cast<const float4*>(lds);  // [m][17][64] float4
+    const float* pa68 = lds + MG * 17 * 256;                   // [m][64]
+    const float* pbl = lds + PA_FLOATS;                        // [m][9][64]
 
     const int NB = a.num_betas;
     const int nparamB = 8 + NB + 3;            // lanes of set B that hold a parameter
@@ -131,15 +163,16 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const bool betaB = lane >= 8 && lane < 8 + NB;
     const bool optB = actB && !(betaB && a.freeze_betas);
 
-    float muA[kPriorMaxGauss], cA[kPriorMaxGauss];
+    float muA[MG], cA[MG];
 #pragma unroll
-    for (int m = 0; m < kPriorMaxGauss; ++m) {
-        muA[m] = m < M ? a.row_const[(0 * kPriorMaxGauss + m) * 64 + lane] : 0.f;
-        cA[m] = m < M ? a.row_const[(1 * kPriorMaxGauss + m) * 64 + lane] : 0.f;
+    for (int m = 0; m < MG; ++m) {
+        muA[m] = m < M ? a.row_const[(0 * MG + m) * 64 + lane] : 0.f;
+        cA[m] = m < M ? a.row_const[(1 * MG + m) * 64 + lane] : 0.f;
     }
     // B rows after the butterfly: lane (r = l&7, s = l>>3) owns row 61+r of component s
-    const float muB = a.row_const[2 * kPriorMaxGauss * 64 + lane];
-    const float cB = a.row_const[2 * kPriorMaxGauss * 64 + 64 + lane];
+    const float muB = a.row_const[2 * MG * 64 + lane];
+    const float cB = a.row_const[2 * MG * 64 + 64 + lane];
+    const int rB = lane & 7, sB = lane >> 3;
 
     // angle prior: sign (0 = not a prior index) for the set-A parameter of this lane
     float angA = 0.f;
@@ -147,23 +180,38 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     for (int i = 0; i < 4; ++i)
         if (lane == 3 + a.angle_index[i]) angA = a.angle_sign[i];
 
-    // joint layout constants
-    const bool isJ = lane < NJ;
-    const int jl = isJ ? lane : 0;
-    const int parent = a.tree[jl * 8 + 0];
-    const int depth = isJ ? a.tree[jl * 8 + 1] : -1;
-    const int ch0 = a.tree[jl * 8 + 2], ch1 = a.tree[jl * 8 + 3], ch2 = a.tree[jl * 8 + 4];
-    float dt[3], dd[3][kMaxBetas];
+    // tree layout constants (host tables, DFS pre-order)
+    const int* lt = a.lane_tab + lane * kLaneTabStride;
+    const int joint = lt[0];                    // joint of this lane, -1 beyond the tree
+    const bool isJ = joint >= 0;
+    const int par_addr = (lt[1] >= 0 ? lt[1] : lane) * 4;
+    const bool has_par = lt[1] >= 0;
+    int anc_addr[kMaxRounds];
+    bool anc_ok[kMaxRounds];
+#pragma unroll
+    for (int r = 0; r < kMaxRounds; ++r) {
+        anc_ok[r] = lt[2 + r] >= 0;
+        anc_addr[r] = (anc_ok[r] ? lt[2 + r] : lane) * 4;
+    }
+    int win_addr[kMaxWinBits];
+    bool win_ok[kMaxWinBits];
+#pragma unroll
+    for (int b = 0; b < kMaxWinBits; ++b) {
+        win_ok[b] = lt[2 + kMaxRounds + b] >= 0;
+        win_addr[b] = (win_ok[b] ? lt[2 + kMaxRounds + b] : lane) * 4;
+    }
+    float dt[3], dd[3][NBT];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        dt[c] = a.dt[jl * 3 + c];
+        dt[c] = a.dt[lane * 3 + c];
 #pragma unroll
-        for (int k = 0; k < kMaxBetas; ++k) dd[c][k] = a.dd[(jl * 3 + c) * kMaxBetas + k];
+        for (int k = 0; k < NBT; ++k) dd[c][k] = a.dd[(lane * 3 + c) * kMaxBetas + k];
     }
-    const int thoff = jl == 0 ? 0 : XS_BODY + 3 * (jl - 1);
+    const int jj = isJ ? joint : 0;
+    const int thoff = jj == 0 ? 0 : XS_BODY + 3 * (jj - 1);
 
-    // targets: lane j holds the target of its joint (or none)
-    const int tk = isJ ? a.lane_target[jl] : -1;
+    // targets: the lane of joint j holds the target of that joint (or none)
+    const int tk = isJ ? a.lane_target[jj] : -1;
     Vec3 tgt = {0.f, 0.f, 0.f};
     float wconf = 0.f;  // w_j^2 c^2
     if (tk >= 0) {
@@ -200,132 +248,150 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 
     for (int it = 0; it < a.num_iters; ++it) {
         const bool last = it == a.num_iters - 1;
+#ifdef K2B_FIT_STAMPS
+        const bool stamp_on = (it == 5) && blockIdx.x == 0 && wave == 0 && g_k2b_stamps != nullptr;
+#endif
+        K2B_STAMP(0);
         // ---- a. parameters -> staging strip ------------------------------------------------
         xs[offA] = x0;
         if (actB) xs[offB] = x1;
         wave_sync();
 
-        // ---- b. joint-layout reads -----------------------------------------------------------
-        const Vec3 th = {xs[thoff], xs[thoff + 1], xs[thoff + 2]};
-        float beta[kMaxBetas];
-#pragma unroll
-        for (int k = 0; k < kMaxBetas; ++k) beta[k] = k < NB ? xs[XS_BETA + k] : 0.f;
-        const Vec3 tr = {xs[XS_TRANSL], xs[XS_TRANSL + 1], xs[XS_TRANSL + 2]};
-
+        K2B_STAMP(1);
         // ---- c. GMM prior: y_m = P_m theta - P_m mu_m for every component ----------------------
-        float acc[kPriorMaxGauss];
+        // rows 0..60 (set A).  Hand-pipelined: block jb+1's nine ds_read_b128 are in flight
+        // while block jb's 32 FMAs issue.
+        float acc[MG];
 #pragma unroll
-        for (int m = 0; m < kPriorMaxGauss; ++m) acc[m] = -cA[m];
-#pragma unroll 1
-        for (int jb = 0; jb < 17; ++jb) {
-            const float4 t4 = *reinterpret_cast<const float4*>(xs + XS_BODY + 4 * jb);
+        for (int m = 0; m < MG; ++m) acc[m] = -cA[m];
+        {
+            const float4* xb4 = reinterpret_cast<const float4*>(xs + XS_BODY);
+            float4 tq[2], pq[2][MG];
+            tq[0] = xb4[0];
 #pragma unroll
-            for (int m = 0; m < kPriorMaxGauss; ++m) {
-                const float4 p4 = *reinterpret_cast<const float4*>(pa + ((m * 17 + jb) * 64 + lane) * 4);
-                acc[m] += p4.x * t4.x;
-                acc[m] += p4.y * t4.y;
-                acc[m] += p4.z * t4.z;
-                acc[m] += p4.w * t4.w;
+            for (int m = 0; m < MG; ++m) pq[0][m] = pa4[(m * 17 + 0) * 64 + lane];
+#pragma unroll
+            for (int jb = 0; jb < 17; ++jb) {
+                const int cur = jb & 1, nxt = cur ^ 1;
+                if (jb + 1 < 17) {
+                    tq[nxt] = xb4[jb + 1];
+#pragma unroll
+                    for (int m = 0; m < MG; ++m) pq[nxt][m] = pa4[(m * 17 + jb + 1) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MG; ++m) {
+                    acc[m] += pq[cur][m].x * tq[cur].x;
+                    acc[m] += pq[cur][m].y * tq[cur].y;
+                    acc[m] += pq[cur][m].z * tq[cur].z;
+                    acc[m] += pq[cur][m].w * tq[cur].w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        K2B_STAMP(2);
+        // column 68 of rows 0..60, then rows 61..68: lane (r, s) sums columns 9s..9s+8 of row
+        // 61+r for every component (same pipelining, one component ahead)
+        float pb[MG];
         {
+            float tb[9], p68[MG], pv[2][9];
             const float t68 = xs[XS_BODY + 68];
 #pragma unroll
-            for (int m = 0; m < kPriorMaxGauss; ++m) acc[m] += pa68[m * 64 + lane] * t68;
-        }
-        // rows 61..68: lane (r, s) sums columns 9s..9s+8 of row 61+r for every component
-        const int rB = lane & 7, sB = lane >> 3;
-        float pb[kPriorMaxGauss];
-        {
-            // keep these 72 L1-resident loads inside the loop: hoisted, they would pin 72 VGPRs
-            const float* pbp = a.pb;
-            asm volatile("" : "+s"(pbp));
-            float tb[9];
+            for (int m = 0; m < MG; ++m) p68[m] = pa68[m * 64 + lane];
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
                 const int col = 9 * sB + c;
-                tb[c] = col < D ? xs[XS_BODY + col] : 0.f;
+                tb[c] = xs[XS_BODY + (col < D ? col : 0)];
             }
 #pragma unroll
-            for (int m = 0; m < kPriorMaxGauss; ++m) {
-                float s = 0.f;
-                if (m < M) {
+            for (int c = 0; c < 9; ++c) pv[0][c] = pbl[(0 * 9 + c) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) s += pbp[(m * 9 + c) * 64 + lane] * tb[c];
+            for (int m = 0; m < MG; ++m) acc[m] += p68[m] * t68;
+#pragma unroll
+            for (int m = 0; m < MG; ++m) {
+                const int cur = m & 1, nxt = cur ^ 1;
+                if (m + 1 < MG) {
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) pv[nxt][c] = pbl[((m + 1) * 9 + c) * 64 + lane];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) s += pv[cur][c] * tb[c];   // image is zero for columns >= 69
                 pb[m] = s;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        K2B_STAMP(3);
         const float yB = butterfly8(pb, lane) - cB;          // component sB, row 61+rB
         const float xB = xs[XS_BODY + 61 + rB];
-        float zB = (xB - muB) * yB;
-        zB += __shfl_xor(zB, 4, kWave);
-        zB += __shfl_xor(zB, 2, kWave);
-        zB += __shfl_xor(zB, 1, kWave);                      // sum over r, component sB
-        float z[kPriorMaxGauss];
+        const float zB = (xB - muB) * yB;
+        float z[MG];
 #pragma unroll
-        for (int m = 0; m < kPriorMaxGauss; ++m) z[m] = bodyA ? (x0 - muA[m]) * acc[m] : 0.f;
-        float q = butterfly8(z, lane);
+        for (int m = 0; m < MG; ++m) z[m] = bodyA ? (x0 - muA[m]) * acc[m] : 0.f;
+        float q = butterfly8(z, lane) + zB;                  // partial of component sB over lanes {r + 8 s}
         q += __shfl_xor(q, 4, kWave);
         q += __shfl_xor(q, 2, kWave);
         q += __shfl_xor(q, 1, kWave);                        // lanes 8m..8m+7: d^T P d of component m
-        const float val = 0.5f * (q + zB) + a.neg_log_nllw[sB < M ? sB : 0];
+        const float val = 0.5f * q + a.neg_log_nllw[sB < M ? sB : 0];
         float best = read_lane(val, 0);
         int mstar = 0;
 #pragma unroll
-        for (int m = 1; m < kPriorMaxGauss; ++m) {
+        for (int m = 1; m < MG; ++m) {
             const float vm = read_lane(val, 8 * m);
             if (m < M && vm < best) { best = vm; mstar = m; }
         }
         float yA = acc[0];
 #pragma unroll
-        for (int m = 1; m < kPriorMaxGauss; ++m) yA = (mstar == m) ? acc[m] : yA;
-        const float yBs = __shfl(yB, rB + 8 * mstar, kWave);  // row 61+lane for lanes < 8
+        for (int m = 1; m < MG; ++m) yA = (mstar == m) ? acc[m] : yA;
+        const float yBs = bperm((rB + 8 * mstar) * 4, yB);   // row 61+lane for lanes < 8
 
-        // ---- d. forward kinematics (joint layout) -----------------------------------------------
+        K2B_STAMP(4);
+        // ---- b/d. tree-layout reads, J(beta), Rodrigues ---------------------------------------------
+        const Vec3 th = {xs[thoff], xs[thoff + 1], xs[thoff + 2]};
+        const Vec3 tr = {xs[XS_TRANSL], xs[XS_TRANSL + 1], xs[XS_TRANSL + 2]};
         Vec3 dj;
         {
+            float beta[NBT];
+#pragma unroll
+            for (int k = 0; k < NBT; ++k) beta[k] = xs[XS_BETA + (k < NB ? k : 0)];
             float e[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float s = dt[c];
 #pragma unroll
-                for (int k = 0; k < kMaxBetas; ++k) s += dd[c][k] * beta[k];
+                for (int k = 0; k < NBT; ++k) s += dd[c][k] * beta[k];   // dd is zero for k >= NB
                 e[c] = s;
             }
             dj = {e[0], e[1], e[2]};
         }
         const Rodrigues rod = rodrigues_fwd(isJ ? th : Vec3{0.f, 0.f, 0.f});
-        Mat3 Rgp, Rg;                      // parent's and own global rotation
-        Vec3 pj = dj;                      // posed joint (without transl)
+        K2B_STAMP(5);
+        // ---- pointer-doubling down-sweep: after round r a lane is composed with 2^(r+1) ancestors ----
+        Mat3 Rg = rod.R;                   // becomes the global rotation
+        Vec3 pj = dj;                      // becomes the posed joint (without transl)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { Rgp.m[i] = (i % 4 == 0) ? 1.f : 0.f; Rg.m[i] = rod.R.m[i]; }
-        if (depth == 0) {
-            float* rec = tree + lane * TREE_REC;
-            *reinterpret_cast<float4*>(rec) = {Rg.m[0], Rg.m[1], Rg.m[2], Rg.m[3]};
-            *reinterpret_cast<float4*>(rec + 4) = {Rg.m[4], Rg.m[5], Rg.m[6], Rg.m[7]};
-            *reinterpret_cast<float4*>(rec + 8) = {Rg.m[8], pj.x, pj.y, pj.z};
-        }
-        for (int lev = 1; lev <= a.max_depth; ++lev) {
-            wave_sync();
-            if (depth == lev) {
-                const float* prec = tree + parent * TREE_REC;
-                const float4 r0 = *reinterpret_cast<const float4*>(prec);
-                const float4 r1 = *reinterpret_cast<const float4*>(prec + 4);
-                const float4 r2 = *reinterpret_cast<const float4*>(prec + 8);
-                Rgp.m[0] = r0.x; Rgp.m[1] = r0.y; Rgp.m[2] = r0.z; Rgp.m[3] = r0.w;
-                Rgp.m[4] = r1.x; Rgp.m[5] = r1.y; Rgp.m[6] = r1.z; Rgp.m[7] = r1.w;
-                Rgp.m[8] = r2.x;
-                const Vec3 pp = {r2.y, r2.z, r2.w};
-                Rg = mul(Rgp, rod.R);
-                pj = pp + mul(Rgp, dj);
-                float* rec = tree + lane * TREE_REC;
-                *reinterpret_cast<float4*>(rec) = {Rg.m[0], Rg.m[1], Rg.m[2], Rg.m[3]};
-                *reinterpret_cast<float4*>(rec + 4) = {Rg.m[4], Rg.m[5], Rg.m[6], Rg.m[7]};
-                *reinterpret_cast<float4*>(rec + 8) = {Rg.m[8], pj.x, pj.y, pj.z};
+        for (int r = 0; r < kMaxRounds; ++r) {
+            if (r < a.num_rounds) {
+                Mat3 Ra;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Ra.m[i] = bperm(anc_addr[r], Rg.m[i]);
+                const Vec3 da = {bperm(anc_addr[r], pj.x), bperm(anc_addr[r], pj.y), bperm(anc_addr[r], pj.z)};
+                if (anc_ok[r]) {
+                    pj = mul(Ra, pj) + da;
+                    Rg = mul(Ra, Rg);
+                }
             }
         }
+        Mat3 Rgp;                          // parent's global rotation (identity at the root)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float v = bperm(par_addr, Rg.m[i]);
+            Rgp.m[i] = has_par ? v : ((i % 4 == 0) ? 1.f : 0.f);
+        }
 
+        K2B_STAMP(6);
         // ---- e. joint loss, its gradient, subtree force / torque sums ------------------------------
         Vec3 gj = {0.f, 0.f, 0.f};
         float part = 0.f;                  // per-lane partial of the loss (summed at the end)
@@ -337,32 +403,39 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             gj = {wconf * 2.f * ex * (s2 * s2) / (dx * dx), wconf * 2.f * ey * (s2 * s2) / (dy * dy),
                   wconf * 2.f * ez * (s2 * s2) / (dz * dz)};
         }
-        Vec3 aj = gj;                      // sum of joint-loss gradients over the subtree
-        Vec3 tj = cross(pj, gj);           // sum of p x g over the subtree
-        if (isJ) {
-            float* rec = up + lane * UP_REC;
-            *reinterpret_cast<float4*>(rec) = {aj.x, aj.y, aj.z, tj.x};
-            *reinterpret_cast<float2*>(rec + 4) = {tj.y, tj.z};
-        }
-        for (int lev = a.max_depth - 1; lev >= 0; --lev) {
-            wave_sync();
-            if (depth == lev && ch0 >= 0) {
+        K2B_STAMP(7);
+        // subtree sums of g and p x g: a subtree is the lane range [t, t + size_t), summed as
+        // power-of-two windows W_b[x] = sum of lanes x .. x + 2^b - 1
+        float sums[6];
+        {
+            const Vec3 pxg = cross(pj, gj);
+            float wcur[6] = {gj.x, gj.y, gj.z, pxg.x, pxg.y, pxg.z};
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int c = s == 0 ? ch0 : (s == 1 ? ch1 : ch2);
-                    if (c >= 0) {
-                        const float4 r0 = *reinterpret_cast<const float4*>(up + c * UP_REC);
-                        const float2 r1 = *reinterpret_cast<const float2*>(up + c * UP_REC + 4);
-                        aj.x += r0.x; aj.y += r0.y; aj.z += r0.z;
-                        tj.x += r0.w; tj.y += r1.x; tj.z += r1.y;
+            for (int i = 0; i < 6; ++i) {
+                wcur[i] = isJ ? wcur[i] : 0.f;
+                const float t = bperm(win_addr[0], wcur[i]);
+                sums[i] = win_ok[0] ? t : 0.f;
+            }
+#pragma unroll
+            for (int b = 1; b < kMaxWinBits; ++b) {
+                if (b < a.num_win_bits) {
+                    const int dn = ((lane + (1 << (b - 1))) & 63) * 4;
+                    float up[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) up[i] = bperm(dn, wcur[i]);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) wcur[i] += up[i];                  // W_b
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const float t = bperm(win_addr[b], wcur[i]);
+                        sums[i] += win_ok[b] ? t : 0.f;
                     }
                 }
-                float* rec = up + lane * UP_REC;
-                *reinterpret_cast<float4*>(rec) = {aj.x, aj.y, aj.z, tj.x};
-                *reinterpret_cast<float2*>(rec + 4) = {tj.y, tj.z};
             }
         }
-        wave_sync();
+        const Vec3 aj = {sums[0], sums[1], sums[2]};
+        const Vec3 tj = {sums[3], sums[4], sums[5]};
+        K2B_STAMP(8);
         // torque about this joint of every force below it, expressed in the parent frame
         const Vec3 torque = tj - cross(pj, aj);
         const Vec3 w = mulT(Rgp, torque);
@@ -375,13 +448,19 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         }
         const Vec3 gth = rodrigues_bwd(rod, th, G);
         const Vec3 gd = mulT(Rgp, aj);     // dL/d(J_j - J_parent)
+        K2B_STAMP(9);
         float gb[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) gb[k] = isJ ? gd.x * dd[0][k] + gd.y * dd[1][k] + gd.z * dd[2][k] : 0.f;
+        for (int k = 0; k < 16; ++k) {
+            const int kk = k < NBT ? k : 0;
+            gb[k] = (isJ && k < NBT) ? gd.x * dd[0][kk] + gd.y * dd[1][kk] + gd.z * dd[2][kk] : 0.f;
+        }
         const float gbeta = butterfly16_sum(gb, lane);   // lanes 4k..4k+3 hold d joint-loss / d beta_k
-        const Vec3 groot = {read_lane(aj.x, 0), read_lane(aj.y, 0), read_lane(aj.z, 0)};  // = d/d transl
+        const Vec3 groot = {read_lane(aj.x, 0), read_lane(aj.y, 0), read_lane(aj.z, 0)};  // root = lane 0: d/d transl
 
-        // ---- f. joint layout -> row layout, then the priors (already in row layout) -------------------
+        K2B_STAMP(10);
+        // ---- f. tree layout -> row layout, then the priors (already in row layout) -------------------
+        wave_sync();
         if (isJ) { xs[thoff] = gth.x; xs[thoff + 1] = gth.y; xs[thoff + 2] = gth.z; }
         if ((lane & 3) == 0 && (lane >> 2) < NB) xs[XS_BETA + (lane >> 2)] = gbeta;
         if (lane == 63) { xs[XS_TRANSL] = groot.x; xs[XS_TRANSL + 1] = groot.y; xs[XS_TRANSL + 2] = groot.z; }
@@ -408,6 +487,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         }
         if (last) loss_total = wave_sum(part) + wpp2 * best;
 
+        K2B_STAMP(11);
         // ---- g. Adam (torch.optim.Adam, single-tensor path) ------------------------------------------
         const float2 co = a.adam_coef[it];     // {lr / (1 - b1^t), sqrt(1 - b2^t)}
         {
@@ -422,6 +502,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             const float denom = sqrtf(v1) / co.y + a.eps;
             x1 = x1 - co.x * (m1 / denom);
         }
+        K2B_STAMP(12);
     }
 
     // ---- 4. results -----------------------------------------------------------------------------------
@@ -441,13 +522,22 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     }
 }
 
+#ifdef K2B_FIT_STAMPS
+extern "C" int k2b_debug_set_stamp_buffer(void* dev_ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k2b_stamps), &dev_ptr, sizeof(void*));
+}
+#endif
+
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
     // enough waves per workgroup to cover the frames with one workgroup per CU, at most MAXW
     int waves = (a.num_frames + a.num_cus - 1) / a.num_cus;
     waves = waves < 1 ? 1 : (waves > MAXW ? MAXW : waves);
     const int blocks = (a.num_frames + waves - 1) / waves;
-    hipLaunchKernelGGL(k2b_fit_world_kernel, dim3(blocks), dim3(waves * 64), 0, stream, a);
+    if (a.num_betas <= 10)
+        hipLaunchKernelGGL(k2b_fit_world_kernel<10>, dim3(blocks), dim3(waves * 64), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k2b_fit_world_kernel<16>, dim3(blocks), dim3(waves * 64), 0, stream, a);
     return hipGetLastError();
 }
 

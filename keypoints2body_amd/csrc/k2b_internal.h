@@ -13,18 +13,23 @@ constexpr int kPriorMaxGauss = 8;   // mixture components resident in LDS
 constexpr int kMaxBetas = 16;
 constexpr int kFitMaxWaves = 8;     // frames (waves) per workgroup
 constexpr int kMaxJoints = 64;
+constexpr int kMaxRounds = 4;       // pointer-doubling rounds: tree depth < 2^4
+constexpr int kMaxWinBits = 5;      // subtree sizes < 2^5
+constexpr int kLaneTabStride = 16;  // ints per lane: joint, parent lane, anc[kMaxRounds], win[kMaxWinBits]
+// LDS image of the prior: rows 0..60 as [8][17][64][4] + [8][64], rows 61..68 as [8][9][64]
+constexpr int kPriorImageFloats = kPriorMaxGauss * (17 * 256 + 64) + kPriorMaxGauss * 9 * 64;
 
 // Kernel arguments of the fused fit (passed by value).
 struct FitArgs {
     // model (device)
-    const float* dt;            // [J][3]     J_template[j] - J_template[parent]  (root: J_template[0])
-    const float* dd;            // [J][3][16] same for J_dirs, zero padded
-    const int* tree;            // [J][8]     parent, depth, child0, child1, child2, -, -, -
-    int max_depth;
+    // tree tables are indexed by LANE: lanes follow the DFS pre-order of the kinematic tree
+    const float* dt;            // [64][3]     J_template[j] - J_template[parent]  (root: J_template[0])
+    const float* dd;            // [64][3][16] same for J_dirs, zero padded
+    const int* lane_tab;        // [64][kLaneTabStride]
+    int num_rounds, num_win_bits;
     int num_betas;
     // prior (device)
-    const float* pa_image;      // LDS image: [8][17][64][4] then [8][64] (see k2b_api.hip)
-    const float* pb;            // [8][9][64]  rows 61..68, lane (r,s) <-> row 61+r, cols 9s..9s+8
+    const float* pa_image;      // LDS image, kPriorImageFloats floats (see k2b_api.hip)
     const float* row_const;     // muA[8][64], cA[8][64], muB[64], cB[64]
     const float* neg_log_nllw;  // [8]
     int num_gauss;

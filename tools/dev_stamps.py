@@ -1,0 +1,32 @@
+"""Diagnostic: per-segment cycle shares of one Adam iteration of the fit kernel
+(diagnostic build tools/libk2b_stamps.so; never used by the product path)."""
+import ctypes, sys, os
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from keypoints2body_amd import native
+native._LIB_PATH = Path(__file__).resolve().parent / "libk2b_stamps.so"
+from tests import helpers as H
+from keypoints2body_amd import synthetic
+
+lib = native.load_library()
+stamps = torch.zeros(64, dtype=torch.int64, device="cuda")
+assert lib.k2b_debug_set_stamp_buffer(ctypes.c_void_p(stamps.data_ptr())) == 0
+m, pr = H.native_model(), H.native_prior()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+p = synthetic.make_poses(B, seed=1)
+j, _ = m.lbs(*map(H.cuda, (p.global_orient, p.body_pose, p.betas, p.transl)), want_vertices=False)
+j3d = j[:, :22].contiguous()
+z = lambda *s: torch.zeros(*s, device="cuda")
+cfg = native.default_fit_config(); cfg.num_iters = 20
+for _ in range(3):
+    native.fit_world(m, pr, cfg, list(range(22)), j3d, None, z(B, 3), z(B, 69), z(B, 10), j3d[:, 0].contiguous())
+torch.cuda.synchronize()
+s = stamps.cpu().numpy()[:13]
+names = ["a/b staging+reads", "GMM A-pass (LDS)", "GMM B rows (global)", "butterflies+argmin", "J(beta)+Rodrigues fwd",
+         "chain down-sweep", "joint loss+grad", "up-sweep", "torque+Rodrigues bwd", "beta grad butterfly",
+         "transpose+priors", "Adam"]
+d = np.diff(s)
+print("total cycles/iter (stamped build):", s[12] - s[0])
+for n, c in zip(names, d):
+    print(f"  {n:28s} {c:7d}  {100.0 * c / (s[12] - s[0]):5.1f}%")
