@@ -13,9 +13,6 @@
 #include "../../include/k2b.h"
 #include "k2b_internal.h"
 
-namespace k2b {
-int skin_bpad(int num_frames);
-}
 
 namespace {
 
@@ -72,8 +69,14 @@ struct k2b_model {
     float *dt = nullptr, *dd = nullptr;
     int* tree = nullptr;
     int num_rounds = 0, num_win_bits = 0;
-    // LBS workspace (grow-only)
-    float *wsA = nullptr, *wsF = nullptr;
+    // LBS B operands (f16 hi/lo, MFMA fragment order) for the whole mesh and for the E extra-joint vertices
+    struct VertexSet {
+        k2b::k2b_half *pdh = nullptr, *pdl = nullptr, *wth = nullptr, *wtl = nullptr;
+        int v_tiles = 0, num = 0;
+    } mesh, extra;
+    int k_steps_x = 0, k_steps_a = 0;
+    // LBS per-frame operand workspace (grow-only)
+    k2b::k2b_half *wsXh = nullptr, *wsXl = nullptr, *wsAh = nullptr, *wsAl = nullptr;
     int ws_bpad = 0;
     // Adam coefficient tables, one per (iters, lr, b1, b2); never overwritten once built
     std::map<std::tuple<int, double, double, double>, float2*> adam_tables;
@@ -141,6 +144,62 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
     HIP_TRY(upload(&m->lbs_weights, lbs_weights, (size_t)V * J));
     HIP_TRY(upload(&m->parents, parents, (size_t)J));
     HIP_TRY(upload(&m->extra_ids, extra_vertex_ids, (size_t)E));
+
+    // LBS operands: B side of the two GEMMs, f16 hi/lo in fragment order (k2b_lbs.hip)
+    {
+        const int P = m->P;
+        const int KX = (P + NB + 2 + 15) / 16, KA = (J + 15) / 16;
+        m->k_steps_x = KX;
+        m->k_steps_a = KA;
+        auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids) -> int {
+            const int n = (int)ids.size();
+            vs.num = n;
+            vs.v_tiles = (n + 31) / 32;
+            const int vp = vs.v_tiles * 32;
+            std::vector<k2b::k2b_half> pdh((size_t)KX * 3 * vp * 16, (k2b::k2b_half)0.f), pdl(pdh.size(), (k2b::k2b_half)0.f);
+            std::vector<k2b::k2b_half> wth((size_t)KA * vp * 16, (k2b::k2b_half)0.f), wtl(wth.size(), (k2b::k2b_half)0.f);
+            for (int i = 0; i < n; ++i) {
+                const int v = ids[i];
+                for (int c = 0; c < 3; ++c) {
+                    auto put = [&](int k, k2b::k2b_half hi, k2b::k2b_half lo) {
+                        const size_t o = ((((size_t)(k >> 4) * 3 + c) * vp + i) * 16) + (k & 15);
+                        pdh[o] = hi;
+                        pdl[o] = lo;
+                    };
+                    auto split = [&](int k, float x) -> float {   // returns what two f16 terms leave over
+                        const float xs = x * k2b::kPdScale;
+                        const k2b::k2b_half hi = (k2b::k2b_half)xs;
+                        const k2b::k2b_half lo = (k2b::k2b_half)(xs - (float)hi);
+                        put(k, hi, lo);
+                        return xs - (float)hi - (float)lo;
+                    };
+                    for (int k = 0; k < P; ++k) split(k, posedirs[(size_t)k * 3 * V + 3 * v + c]);
+                    for (int k = 0; k < NB; ++k) split(P + k, shapedirs[((size_t)v * 3 + c) * NB + k]);
+                    const float rest = split(P + NB, v_template[(size_t)v * 3 + c]);
+                    // the template is metre-scale: keep its third term as an extra K row (feature = 1)
+                    const k2b::k2b_half rh = (k2b::k2b_half)rest;
+                    put(P + NB + 1, rh, (k2b::k2b_half)(rest - (float)rh));
+                }
+                for (int j = 0; j < J; ++j) {
+                    const float w = lbs_weights[(size_t)v * J + j];
+                    const k2b::k2b_half hi = (k2b::k2b_half)w;
+                    const size_t o = (((size_t)(j >> 4) * vp + i) * 16) + (j & 15);
+                    wth[o] = hi;
+                    wtl[o] = (k2b::k2b_half)(w - (float)hi);
+                }
+            }
+            hipError_t e;
+            if ((e = upload(&vs.pdh, pdh.data(), pdh.size())) != hipSuccess) return (int)e;
+            if ((e = upload(&vs.pdl, pdl.data(), pdl.size())) != hipSuccess) return (int)e;
+            if ((e = upload(&vs.wth, wth.data(), wth.size())) != hipSuccess) return (int)e;
+            if ((e = upload(&vs.wtl, wtl.data(), wtl.size())) != hipSuccess) return (int)e;
+            return 0;
+        };
+        std::vector<int> all(V), ex(extra_vertex_ids, extra_vertex_ids + E);
+        for (int v = 0; v < V; ++v) all[v] = v;
+        if (build(m->mesh, all) != 0 || (E > 0 && build(m->extra, ex) != 0))
+            return fail(K2B_ERR_HIP, "k2b_model_create: uploading LBS operands failed");
+    }
 
     // J x V contraction on the matrix cores
     {
@@ -231,8 +290,11 @@ void k2b_model_destroy(k2b_model* m) {
     if (!m) return;
     (void)hipDeviceSynchronize();
     float* fl[] = {m->v_template, m->shapedirs, m->posedirs, m->j_regressor, m->lbs_weights, m->j_template,
-                   m->j_dirs, m->dt, m->dd, m->wsA, m->wsF};
+                   m->j_dirs, m->dt, m->dd};
     for (float* p : fl) if (p) (void)hipFree(p);
+    k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->mesh.wth, m->mesh.wtl, m->extra.pdh, m->extra.pdl,
+                           m->extra.wth, m->extra.wtl, m->wsXh, m->wsXl, m->wsAh, m->wsAl};
+    for (k2b::k2b_half* p : hl) if (p) (void)hipFree(p);
     if (m->parents) (void)hipFree(m->parents);
     if (m->extra_ids) (void)hipFree(m->extra_ids);
     if (m->tree) (void)hipFree(m->tree);
@@ -420,39 +482,50 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     if (!go || !bp || !be) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_lbs: NULL parameter buffer");
     if (!joints_out && !vertices_out) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_lbs: no output requested");
     hipStream_t stream = (hipStream_t)stream_v;
-    const int bpad = k2b::skin_bpad(B);
+    const int bpad = k2b::lbs_frames_padded(B);
     {
         std::lock_guard<std::mutex> lk(m->mu);
         if (bpad > m->ws_bpad) {
             HIP_TRY(hipDeviceSynchronize());
-            if (m->wsA) HIP_TRY(hipFree(m->wsA));
-            if (m->wsF) HIP_TRY(hipFree(m->wsF));
-            m->wsA = m->wsF = nullptr;
+            k2b::k2b_half** ws[] = {&m->wsXh, &m->wsXl, &m->wsAh, &m->wsAl};
+            for (auto w : ws) { if (*w) HIP_TRY(hipFree(*w)); *w = nullptr; }
             m->ws_bpad = 0;
-            HIP_TRY(hipMalloc((void**)&m->wsA, (size_t)m->J * 12 * bpad * sizeof(float)));
-            HIP_TRY(hipMalloc((void**)&m->wsF, (size_t)m->P * bpad * sizeof(float)));
-            HIP_TRY(hipMemset(m->wsA, 0, (size_t)m->J * 12 * bpad * sizeof(float)));
-            HIP_TRY(hipMemset(m->wsF, 0, (size_t)m->P * bpad * sizeof(float)));
+            const size_t nx = (size_t)m->k_steps_x * bpad * 16, na = (size_t)12 * m->k_steps_a * bpad * 16;
+            HIP_TRY(hipMalloc((void**)&m->wsXh, nx * sizeof(k2b::k2b_half)));
+            HIP_TRY(hipMalloc((void**)&m->wsXl, nx * sizeof(k2b::k2b_half)));
+            HIP_TRY(hipMalloc((void**)&m->wsAh, na * sizeof(k2b::k2b_half)));
+            HIP_TRY(hipMalloc((void**)&m->wsAl, na * sizeof(k2b::k2b_half)));
+            // rows of padding frames are never written by the set-up kernel: keep them finite
+            HIP_TRY(hipMemset(m->wsXh, 0, nx * sizeof(k2b::k2b_half)));
+            HIP_TRY(hipMemset(m->wsXl, 0, nx * sizeof(k2b::k2b_half)));
+            HIP_TRY(hipMemset(m->wsAh, 0, na * sizeof(k2b::k2b_half)));
+            HIP_TRY(hipMemset(m->wsAl, 0, na * sizeof(k2b::k2b_half)));
             m->ws_bpad = bpad;
         }
     }
     k2b::PoseArgs pa{};
     pa.j_template = m->j_template; pa.j_dirs = m->j_dirs; pa.parents = m->parents;
-    pa.num_joints = m->J; pa.num_betas = m->NB; pa.num_out_joints = m->J + m->E; pa.num_frames = B;
+    pa.num_joints = m->J; pa.num_betas = m->NB; pa.num_out_joints = m->J + m->E;
+    pa.num_frames = B; pa.frames_padded = bpad; pa.k_steps_x = m->k_steps_x; pa.k_steps_a = m->k_steps_a;
     pa.go = go; pa.bp = bp; pa.be = be; pa.tr = tr;
-    pa.A = m->wsA; pa.feat = m->wsF; pa.joints_out = joints_out;
-    k2b::SkinArgs sa{};
-    sa.num_vertices = m->V; sa.num_joints = m->J; sa.num_betas = m->NB; sa.num_pose_feats = m->P;
-    sa.v_template = m->v_template; sa.shapedirs = m->shapedirs; sa.posedirs = m->posedirs; sa.lbs_weights = m->lbs_weights;
-    sa.num_frames = B; sa.be = be; sa.tr = tr; sa.A = m->wsA; sa.feat = m->wsF;
+    pa.xh = m->wsXh; pa.xl = m->wsXl; pa.ah = m->wsAh; pa.al = m->wsAl; pa.joints_out = joints_out;
     HIP_TRY(k2b::launch_pose_setup(pa, stream));
+    auto skin = [&](const k2b_model::VertexSet& vs, float* out, int stride, int row0) -> hipError_t {
+        k2b::SkinArgs sa{};
+        sa.pdh = vs.pdh; sa.pdl = vs.pdl; sa.wth = vs.wth; sa.wtl = vs.wtl;
+        sa.v_tiles = vs.v_tiles; sa.num_out = vs.num;
+        sa.k_steps_x = m->k_steps_x; sa.k_steps_a = m->k_steps_a;
+        sa.num_frames = B; sa.frames_padded = bpad; sa.f_tiles = bpad / 32;
+        sa.xh = m->wsXh; sa.xl = m->wsXl; sa.ah = m->wsAh; sa.al = m->wsAl;
+        sa.tr = tr; sa.out = out; sa.out_stride = stride; sa.out_row0 = row0;
+        return k2b::launch_skin(sa, stream);
+    };
     if (vertices_out) {
-        sa.vertex_ids = nullptr; sa.num_out = m->V; sa.out = vertices_out; sa.out_stride = m->V; sa.out_row0 = 0;
-        HIP_TRY(k2b::launch_skin(sa, stream));
-    }
-    if (joints_out && m->E > 0) {
-        sa.vertex_ids = m->extra_ids; sa.num_out = m->E; sa.out = joints_out; sa.out_stride = m->J + m->E; sa.out_row0 = m->J;
-        HIP_TRY(k2b::launch_skin(sa, stream));
+        HIP_TRY(skin(m->mesh, vertices_out, m->V, 0));
+        if (joints_out && m->E > 0)
+            HIP_TRY(k2b::launch_gather_joints(vertices_out, m->extra_ids, joints_out, B, m->V, m->J, m->E, stream));
+    } else if (joints_out && m->E > 0) {
+        HIP_TRY(skin(m->extra, joints_out, m->J + m->E, m->J));
     }
     return K2B_OK;
 }

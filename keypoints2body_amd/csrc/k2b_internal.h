@@ -53,39 +53,43 @@ struct FitArgs {
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);
 
-// Pose set-up for LBS: per frame the relative transforms A_j (3x4), the pose feature
-// vec(R_1..R_{J-1} - I) and the posed kinematic joints (+ transl).
+// LBS operands are f16 hi/lo pairs in MFMA fragment order: [k-step][row][16 halfs].
+typedef _Float16 k2b_half;
+constexpr float kPdScale = 256.0f;   // power-of-two scale of the vertex-GEMM B operand (keeps f16 lo terms normal)
+
+// Pose set-up for LBS: per frame the relative transforms A_j (3x4) and the feature vector
+// X = [vec(R_1..R_{J-1} - I) | beta | 1 | 1] as f16 hi/lo MFMA operands, plus the posed
+// kinematic joints (+ transl).
 struct PoseArgs {
     const float* j_template;   // [J][3]
     const float* j_dirs;       // [J][3][NB]
     const int* parents;        // [J]
     int num_joints, num_betas, num_out_joints;
-    int num_frames;
+    int num_frames, frames_padded;
+    int k_steps_x, k_steps_a;  // 16-deep k-steps of the vertex GEMM (features) and of the transform GEMM (joints)
     const float *go, *bp, *be, *tr;  // tr may be null
-    float* A;                  // [B][J][12]
-    float* feat;               // [B][9(J-1)]
-    float* joints_out;         // [B][num_out_joints][3] (first J rows written)
+    k2b_half *xh, *xl;         // [k_steps_x][frames_padded][16]
+    k2b_half *ah, *al;         // [12][k_steps_a][frames_padded][16]
+    float* joints_out;         // [B][num_out_joints][3] (first J rows written) or null
 };
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream);
+int lbs_frames_padded(int num_frames);
 
+// One vertex set (the whole mesh, or the E vertex-selected joints) as B operands.
 struct SkinArgs {
-    int num_vertices, num_joints, num_betas, num_pose_feats;
-    const float* v_template;   // [V][3]
-    const float* shapedirs;    // [V][3][NB]
-    const float* posedirs;     // [P][3V]
-    const float* lbs_weights;  // [V][J]
-    const int* vertex_ids;     // optional subset [n_out] (null: all V vertices in order)
-    int num_out;               // vertices produced per frame
-    int num_frames;
-    const float* be;           // [B][NB]
-    const float* tr;           // [B][3] or null
-    const float* A;            // [B][J][12]
-    const float* feat;         // [B][P]
-    float* out;                // [B][out_stride][3] rows out_row0 .. out_row0+num_out-1
+    const k2b_half *pdh, *pdl;   // [k_steps_x][3][v_tiles*32][16]  (posedirs ; shapedirs ; template ; residual) * kPdScale
+    const k2b_half *wth, *wtl;   // [k_steps_a][v_tiles*32][16]     skinning weights, k = joint
+    int v_tiles, num_out;        // 32-vertex tiles, real vertex count of the set
+    int k_steps_x, k_steps_a;
+    int num_frames, frames_padded, f_tiles;
+    const k2b_half *xh, *xl, *ah, *al;   // per-frame operands from the pose set-up
+    const float* tr;             // [B][3] or null
+    float* out;                  // [B][out_stride][3], rows out_row0 .. out_row0 + num_out - 1
     int out_stride, out_row0;
 };
 hipError_t launch_skin(const SkinArgs& a, hipStream_t stream);
-int skin_bpad(int num_frames);  // row stride of the frame-minor A / feat workspaces
+hipError_t launch_gather_joints(const float* verts, const int* ids, float* joints, int num_frames, int V, int J, int E,
+                                hipStream_t stream);
 
 // J x V contraction on the matrix cores: out[J][N] = j_regressor[J][V] . rhs[V][N].
 hipError_t launch_jreg_contract(const float* j_regressor, const float* rhs, float* out, int J, int V, int N,

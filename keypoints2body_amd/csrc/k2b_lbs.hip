@@ -5,22 +5,40 @@
 // lbs(): shape blend, pose-corrective blend, kinematic chain, linear blend skinning,
 // vertex-selected extra joints, translation.  CPU twin: oracle/smpl_torch.py.
 //
-// Two kernels per call:
-//   k2b_pose_setup_kernel  one 64-lane workgroup per frame, lane j = joint j: Rodrigues,
-//                          J(beta), global transform by walking the ancestor chain from LDS,
-//                          relative transforms A_j and the pose feature, both stored
-//                          frame-minor ([.][Bpad]) so the skinning kernel can fetch a group
-//                          of frames with one scalar load.
-//   k2b_skin_kernel        thread = vertex, kSkinFrames frames per thread: every posedirs /
-//                          shapedirs / weight element fetched once per frame group and reused
-//                          from registers; per-frame operands arrive through the scalar path.
+// The two contractions of LBS are GEMMs over (frames x vertices):
+//   v_posed[f][v][c] = sum_k X[f][k] * Pd[k][v][c]      K = 9(J-1) + NB + 2   (224 for SMPL)
+//        X = [vec(R_1..R_{J-1} - I) | beta | 1 | 1],  Pd = [posedirs ; shapedirs ; v_template ; residual]
+//   T[f][v][e]       = sum_j W[v][j] * A[f][j][e]       K = J (24), e = 12 entries of the 3x4 transform
+// and the result is v[f][v] = T[f][v] [v_posed; 1] + transl[f].
+//
+// Both run on the matrix cores.  fp32-input MFMA issues at the fp32 VALU rate, so operands are
+// split into two f16 terms (x = hi + lo, ~22 mantissa bits) and each product takes three
+// v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): 3/16 of the fp32 MFMA time
+// at fp32-level accuracy (|error| ~ 1e-6 m on metre-scale vertices; tests/test_gpu_parity.py).
+//
+// Tiling: one wave owns a 32-frame x 32-vertex tile.  MFMA orientation D[frame][vertex]: the
+// accumulator of lane l holds 16 frames of ONE vertex (column l & 31), so the skinning epilogue
+// (T applied to v_posed) is a per-lane computation with no cross-lane traffic.  Operand
+// fragments are stored k-step-major ([ks][row][16 halfs]) so that a wave's fragment load is one
+// contiguous 1 KiB read.
+#include <hip/hip_fp16.h>
+
 #include "k2b_internal.h"
 
 namespace k2b {
 
-constexpr int kSkinFrames = 8;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a, int bpad) {
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pose set-up: one 64-lane workgroup per frame, lane j = joint j.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     __shared__ float sR[kMaxJoints][9];
     __shared__ float sd[kMaxJoints][3];
     __shared__ int spar[kMaxJoints];
@@ -28,6 +46,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a, in
     const int j = threadIdx.x;
     const int J = a.num_joints, NB = a.num_betas;
     const bool act = j < J;
+    const int bp = a.frames_padded;
 
     Vec3 th = {0.f, 0.f, 0.f};
     Vec3 Jj = {0.f, 0.f, 0.f}, Jp = {0.f, 0.f, 0.f};
@@ -58,6 +77,30 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a, in
         spar[j] = par;
     }
     __syncthreads();
+
+    // X operand of the vertex GEMM, f16 hi/lo, fragment layout [ks][frame][16]
+    auto put_x = [&](int k, float x) {
+        _Float16 hi, lo;
+        split_f16(x, hi, lo);
+        const size_t o = ((size_t)(k >> 4) * bp + f) * 16 + (k & 15);
+        a.xh[o] = hi;
+        a.xl[o] = lo;
+    };
+    const int P = 9 * (J - 1);
+    if (act && j > 0) {
+        for (int i = 0; i < 9; ++i) put_x((j - 1) * 9 + i, rod.R.m[i] - ((i % 4 == 0) ? 1.f : 0.f));
+    }
+    for (int k = P + j; k < a.k_steps_x * 16; k += 64) {   // betas, the two constant-1 features, zero padding
+        const float x = k < P + NB ? a.be[(size_t)f * NB + (k - P)] : (k < P + NB + 2 ? 1.f : 0.f);
+        put_x(k, x);
+    }
+    // zero rows of the A operand for the padded joints J .. 16*k_steps_a - 1
+    for (int idx = j; idx < (a.k_steps_a * 16 - J) * 12; idx += 64) {
+        const int jj = J + idx / 12, e = idx % 12;
+        const size_t o = (((size_t)e * a.k_steps_a + (jj >> 4)) * bp + f) * 16 + (jj & 15);
+        a.ah[o] = (_Float16)0.f;
+        a.al[o] = (_Float16)0.f;
+    }
     if (!act) return;
 
     // global transform: compose towards the root
@@ -70,14 +113,16 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a, in
         pg = mul(Ra, pg) + da;
         Rg = mul(Ra, Rg);
     }
-    // A_j = [Rg | pg - Rg J_j]
+    // A_j = [Rg | pg - Rg J_j], f16 hi/lo, fragment layout [e][ks][frame][16] with k = joint
     const Vec3 rj = mul(Rg, Jj);
     const float At[12] = {Rg.m[0], Rg.m[1], Rg.m[2], pg.x - rj.x, Rg.m[3], Rg.m[4], Rg.m[5], pg.y - rj.y,
                           Rg.m[6], Rg.m[7], Rg.m[8], pg.z - rj.z};
-    for (int e = 0; e < 12; ++e) a.A[((size_t)j * 12 + e) * bpad + f] = At[e];
-    if (j > 0) {
-        for (int i = 0; i < 9; ++i)
-            a.feat[((size_t)(j - 1) * 9 + i) * bpad + f] = rod.R.m[i] - ((i % 4 == 0) ? 1.f : 0.f);
+    for (int e = 0; e < 12; ++e) {
+        _Float16 hi, lo;
+        split_f16(At[e], hi, lo);
+        const size_t o = (((size_t)e * a.k_steps_a + (j >> 4)) * bp + f) * 16 + (j & 15);
+        a.ah[o] = hi;
+        a.al[o] = lo;
     }
     if (a.joints_out) {
         float* o = a.joints_out + ((size_t)f * a.num_out_joints + j) * 3;
@@ -87,120 +132,152 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a, in
     }
 }
 
-template <int J>
-__global__ __launch_bounds__(256) void k2b_skin_kernel(const SkinArgs a, int bpad) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.num_out) return;
-    const int v = a.vertex_ids ? a.vertex_ids[i] : i;
-    const int f0 = blockIdx.y * kSkinFrames;
-    const int NB = a.num_betas, P = a.num_pose_feats, V = a.num_vertices;
-    const float* __restrict__ feat = a.feat;
-    const float* __restrict__ Am = a.A;
+// ---------------------------------------------------------------------------------------------
+// Vertex kernel: one wave per (32 frames x 32 vertices) tile, 4 waves per workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunkPairs = 8;   // frame-tile pairs (64 frames each) per L2-resident chunk
 
-    float w[J];
+__device__ __forceinline__ half8 ld_frag(const _Float16* base, size_t row_index, int h) {
+    return *reinterpret_cast<const half8*>(base + row_index * 16 + 8 * h);
+}
+
+__global__ __launch_bounds__(256, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    // workgroup = 2 frame tiles x 2 vertex tiles.  Rasterisation for the 8 per-XCD L2s (blocks are
+    // dealt round-robin over the XCDs, so b % 8 labels blocks that share an L2): each label owns
+    // every 8th vertex-tile pair, and inside a chunk of kChunkPairs frame-tile pairs the frame
+    // index runs fastest - the 172 KB of vertex operands of one pair stay L2-resident while the
+    // chunk's frames sweep over them, and the chunk's per-frame operands (1.2 MB) stay resident
+    // while the vertex pairs advance.  Placement affects speed only.
+    const int vpairs = (a.v_tiles + 1) / 2, fpairs = (a.f_tiles + 1) / 2;
+    const int vl = (vpairs + 7) / 8;                       // vertex-tile pairs per label
+    const int label = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int chunk = i / (vl * kChunkPairs), rem = i % (vl * kChunkPairs);
+    const int vpair = (rem / kChunkPairs) * 8 + label, fpair = chunk * kChunkPairs + rem % kChunkPairs;
+    if (vpair >= vpairs || fpair >= fpairs) return;
+    const int vt = vpair * 2 + (wave & 1);
+    const int ft = fpair * 2 + (wave >> 1);
+    if (vt >= a.v_tiles || ft >= a.f_tiles) return;
+    const int vp = a.v_tiles * 32;          // padded vertex count of this vertex set
+    const int bp = a.frames_padded;
+    const int KS = a.k_steps_x, KA = a.k_steps_a;
+    const size_t frow = (size_t)ft * 32 + col;      // A-operand row (frame) of this lane
+    const size_t vrow = (size_t)vt * 32 + col;      // B-operand column (vertex) of this lane
+
+    // ---- 1. v_posed * 256 = X . Pd  (three coordinates) -------------------------------------------
+    floatx16 acc[3];
 #pragma unroll
-    for (int j = 0; j < J; ++j) w[j] = a.lbs_weights[(size_t)v * J + j];
-
-    float vp[kSkinFrames][3];
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
     {
-        const float t0 = a.v_template[v * 3], t1 = a.v_template[v * 3 + 1], t2 = a.v_template[v * 3 + 2];
+        half8 xh = ld_frag(a.xh, frow, h), xl = ld_frag(a.xl, frow, h);
+        half8 ph[3], pl[3];
 #pragma unroll
-        for (int fr = 0; fr < kSkinFrames; ++fr) { vp[fr][0] = t0; vp[fr][1] = t1; vp[fr][2] = t2; }
-        for (int k = 0; k < NB; ++k) {
-            const float s0 = a.shapedirs[((size_t)v * 3 + 0) * NB + k], s1 = a.shapedirs[((size_t)v * 3 + 1) * NB + k],
-                        s2 = a.shapedirs[((size_t)v * 3 + 2) * NB + k];
+        for (int c = 0; c < 3; ++c) {
+            ph[c] = ld_frag(a.pdh, (size_t)c * vp + vrow, h);
+            pl[c] = ld_frag(a.pdl, (size_t)c * vp + vrow, h);
+        }
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 nxh = xh, nxl = xl, nph[3], npl[3];
 #pragma unroll
-            for (int fr = 0; fr < kSkinFrames; ++fr) {
-                const int f = f0 + fr < a.num_frames ? f0 + fr : a.num_frames - 1;
-                const float b = a.be[(size_t)f * NB + k];
-                vp[fr][0] += s0 * b; vp[fr][1] += s1 * b; vp[fr][2] += s2 * b;
+            for (int c = 0; c < 3; ++c) { nph[c] = ph[c]; npl[c] = pl[c]; }
+            if (ks + 1 < KS) {
+                nxh = ld_frag(a.xh, (size_t)(ks + 1) * bp + frow, h);
+                nxl = ld_frag(a.xl, (size_t)(ks + 1) * bp + frow, h);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    nph[c] = ld_frag(a.pdh, ((size_t)(ks + 1) * 3 + c) * vp + vrow, h);
+                    npl[c] = ld_frag(a.pdl, ((size_t)(ks + 1) * 3 + c) * vp + vrow, h);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, ph[c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, pl[c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, ph[c], acc[c], 0, 0, 0);
+            }
+            xh = nxh; xl = nxl;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ph[c] = nph[c]; pl[c] = npl[c]; }
+        }
+    }
+    const float inv_scale = 1.0f / kPdScale;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] *= inv_scale;
+
+    // ---- 2. per output coordinate r: T[4r..4r+3] = A . W^T, then out_r = T . [v_posed; 1] -----------
+    const int v = vt * 32 + col;                       // index inside this vertex set
+    const bool v_ok = v < a.num_out;
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+        floatx16 t4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t4[e][i] = 0.f;
+        for (int ks = 0; ks < KA; ++ks) {
+            const half8 wh = ld_frag(a.wth, (size_t)ks * vp + vrow, h), wl = ld_frag(a.wtl, (size_t)ks * vp + vrow, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t row = ((size_t)(4 * r + e) * KA + ks) * bp + frow;
+                const half8 ah = ld_frag(a.ah, row, h), al = ld_frag(a.al, row, h);
+                t4[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, t4[e], 0, 0, 0);
+                t4[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, t4[e], 0, 0, 0);
+                t4[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, t4[e], 0, 0, 0);
+            }
+        }
+        // C/D map of 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = ft * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (v_ok && f < a.num_frames) {
+                float o = t4[0][i] * acc[0][i] + t4[1][i] * acc[1][i] + t4[2][i] * acc[2][i] + t4[3][i];
+                if (a.tr) o += a.tr[(size_t)f * 3 + r];
+                a.out[((size_t)f * a.out_stride + a.out_row0 + v) * 3 + r] = o;
             }
         }
     }
-    // pose-corrective blend: v_posed += feat . posedirs[:, 3v..3v+2]
-    const float* __restrict__ pd = a.posedirs + (size_t)3 * v;
-#pragma unroll 4
-    for (int k = 0; k < P; ++k) {
-        const float p0 = pd[(size_t)k * 3 * V], p1 = pd[(size_t)k * 3 * V + 1], p2 = pd[(size_t)k * 3 * V + 2];
-        const float* __restrict__ fk = feat + (size_t)k * bpad + f0;   // wave-uniform address
-#pragma unroll
-        for (int fr = 0; fr < kSkinFrames; ++fr) {
-            const float ff = fk[fr];
-            vp[fr][0] += ff * p0; vp[fr][1] += ff * p1; vp[fr][2] += ff * p2;
-        }
-    }
-    // skinning: T = sum_j w_j A_j ; out = T [v_posed; 1] + transl
-#pragma unroll
-    for (int fr = 0; fr < kSkinFrames; ++fr) {
-        const int f = f0 + fr;
-        if (f >= a.num_frames) break;
-        float T[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-#pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] += w[j] * Am[((size_t)j * 12 + e) * bpad + f];
-        }
-        float ox = T[0] * vp[fr][0] + T[1] * vp[fr][1] + T[2] * vp[fr][2] + T[3];
-        float oy = T[4] * vp[fr][0] + T[5] * vp[fr][1] + T[6] * vp[fr][2] + T[7];
-        float oz = T[8] * vp[fr][0] + T[9] * vp[fr][1] + T[10] * vp[fr][2] + T[11];
-        if (a.tr) { ox += a.tr[(size_t)f * 3]; oy += a.tr[(size_t)f * 3 + 1]; oz += a.tr[(size_t)f * 3 + 2]; }
-        float* o = a.out + ((size_t)f * a.out_stride + a.out_row0 + i) * 3;
-        o[0] = ox; o[1] = oy; o[2] = oz;
-    }
 }
 
-// generic-J fallback (weights streamed from memory)
-__global__ __launch_bounds__(256) void k2b_skin_kernel_anyj(const SkinArgs a, int bpad) {
+// joints J..J+E-1 := vertices[extra ids] (when the full mesh has just been produced)
+__global__ void k2b_gather_joints_kernel(const float* __restrict__ verts, const int* __restrict__ ids, float* joints,
+                                         int num_frames, int V, int J, int E) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.num_out) return;
-    const int v = a.vertex_ids ? a.vertex_ids[i] : i;
-    const int NB = a.num_betas, P = a.num_pose_feats, V = a.num_vertices, J = a.num_joints;
-    for (int fr = 0; fr < kSkinFrames; ++fr) {
-        const int f = blockIdx.y * kSkinFrames + fr;
-        if (f >= a.num_frames) break;
-        float vp[3];
-        for (int c = 0; c < 3; ++c) {
-            float s = a.v_template[v * 3 + c];
-            for (int k = 0; k < NB; ++k) s += a.shapedirs[((size_t)v * 3 + c) * NB + k] * a.be[(size_t)f * NB + k];
-            vp[c] = s;
-        }
-        for (int k = 0; k < P; ++k) {
-            const float ff = a.feat[(size_t)k * bpad + f];
-            for (int c = 0; c < 3; ++c) vp[c] += ff * a.posedirs[(size_t)k * 3 * V + 3 * v + c];
-        }
-        float T[12];
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-        for (int j = 0; j < J; ++j) {
-            const float wj = a.lbs_weights[(size_t)v * J + j];
-            for (int e = 0; e < 12; ++e) T[e] += wj * a.A[((size_t)j * 12 + e) * bpad + f];
-        }
-        float o3[3];
-        for (int r = 0; r < 3; ++r)
-            o3[r] = T[4 * r] * vp[0] + T[4 * r + 1] * vp[1] + T[4 * r + 2] * vp[2] + T[4 * r + 3] +
-                    (a.tr ? a.tr[(size_t)f * 3 + r] : 0.f);
-        float* o = a.out + ((size_t)f * a.out_stride + a.out_row0 + i) * 3;
-        o[0] = o3[0]; o[1] = o3[1]; o[2] = o3[2];
-    }
+    if (i >= num_frames * E) return;
+    const int f = i / E, e = i % E;
+    const float* s = verts + ((size_t)f * V + ids[e]) * 3;
+    float* d = joints + ((size_t)f * (J + E) + J + e) * 3;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
 }
 
-int skin_bpad(int num_frames) { return (num_frames + kSkinFrames - 1) / kSkinFrames * kSkinFrames; }
+int lbs_frames_padded(int num_frames) { return (num_frames + 31) / 32 * 32; }
 
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k2b_pose_setup_kernel, dim3(a.num_frames), dim3(64), 0, stream, a, skin_bpad(a.num_frames));
+    hipLaunchKernelGGL(k2b_pose_setup_kernel, dim3(a.num_frames), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_skin(const SkinArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0 || a.num_out <= 0) return hipSuccess;
-    const dim3 grid((a.num_out + 255) / 256, (a.num_frames + kSkinFrames - 1) / kSkinFrames);
-    const int bpad = skin_bpad(a.num_frames);
-    if (a.num_joints == 24)
-        hipLaunchKernelGGL(k2b_skin_kernel<24>, grid, dim3(256), 0, stream, a, bpad);
-    else
-        hipLaunchKernelGGL(k2b_skin_kernel_anyj, grid, dim3(256), 0, stream, a, bpad);
+    const int vpairs = (a.v_tiles + 1) / 2, fpairs = (a.f_tiles + 1) / 2;
+    const int vl = (vpairs + 7) / 8, chunks = (fpairs + kChunkPairs - 1) / kChunkPairs;
+    const dim3 grid(8 * vl * kChunkPairs * chunks);
+    hipLaunchKernelGGL(k2b_lbs_mfma_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_joints(const float* verts, const int* ids, float* joints, int num_frames, int V, int J, int E,
+                                hipStream_t stream) {
+    if (num_frames <= 0 || E <= 0) return hipSuccess;
+    const int n = num_frames * E;
+    hipLaunchKernelGGL(k2b_gather_joints_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, verts, ids, joints,
+                       num_frames, V, J, E);
     return hipGetLastError();
 }
 
