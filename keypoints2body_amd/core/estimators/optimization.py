@@ -1,0 +1,56 @@
+"""Optimisation-based estimator: routes ``fit_frame`` to the HIP world-space fitter.
+
+Counterpart of the reference's ``OptimizationEstimator``
+(reference ``keypoints2body/core/estimators/optimization.py:14-85``): it picks the fitter
+from ``model_type`` / ``coordinate_mode`` and injects ``joint_loss_weight``,
+``pose_preserve_weight`` and ``freeze_betas`` from the frame config on every call.
+Only the world-space SMPL-family fitter exists on the HIP engine so far; the other
+branches of the reference's dispatch raise ``NotImplementedError`` naming what is missing.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ...models.smpl_data import BodyModelFitResult, BodyModelParams
+from ..config import FrameOptimizeConfig
+from ..fitters.world_space import WorldSpaceFitter
+
+
+class OptimizationEstimator:
+    def __init__(self, model, frame_config: FrameOptimizeConfig, device=None, model_type: str = "smpl",
+                 pose_prior=None):
+        self.frame_config = frame_config
+        if model_type in ("mano", "flame"):
+            raise NotImplementedError(
+                f"body_model='{model_type}': the MANO/FLAME fitters (reference core/fitters/misc_models.py) "
+                "are outside the HIP engine's scope")
+        if frame_config.coordinate_mode == "camera":
+            raise NotImplementedError(
+                "coordinate_mode='camera': the two-stage camera-space fitter (reference "
+                "core/fitters/camera_space.py) is not built on the HIP engine yet; use coordinate_mode='world'")
+        self._fitter = WorldSpaceFitter(
+            smpl_model=model, step_size=frame_config.step_size, num_iters_first=frame_config.num_iters_first,
+            num_iters_followup=frame_config.num_iters_followup, use_lbfgs=frame_config.use_lbfgs,
+            joints_category=frame_config.joints_category, device=device,
+            pose_prior_num_gaussians=frame_config.pose_prior_num_gaussians, pose_prior=pose_prior)
+
+    @property
+    def fitter(self) -> WorldSpaceFitter:
+        return self._fitter
+
+    def _weights(self):
+        c = self.frame_config
+        return dict(joint_loss_weight=c.joint_loss_weight, pose_preserve_weight=c.pose_preserve_weight,
+                    freeze_betas=c.freeze_betas)
+
+    def fit_frame(self, init_params: BodyModelParams, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor],
+                  seq_ind: int, target_model_indices: Optional[torch.Tensor] = None) -> BodyModelFitResult:
+        return self._fitter.fit_frame(init_params=init_params, j3d=j3d, conf_3d=conf_3d, seq_ind=seq_ind,
+                                      target_model_indices=target_model_indices, **self._weights())
+
+    def fit_batch(self, init_params, j3d, conf_3d, seq_ind, target_model_indices=None, per_frame_conf=False):
+        """B independent frames in one launch (not part of the reference protocol)."""
+        return self._fitter.fit_batch(init_params, j3d, conf_3d, seq_ind, target_model_indices,
+                                      per_frame_conf=per_frame_conf, **self._weights())

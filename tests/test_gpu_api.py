@@ -1,0 +1,120 @@
+"""GPU: the public API (optimize_params_frame / optimize_params_sequence) end to end on the
+HIP engine, against reference goldens and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import keypoints2body_amd as k2b
+from keypoints2body_amd.core.config import FrameOptimizeConfig, SequenceOptimizeConfig
+from keypoints2body_amd.models.body_model import BodyModel
+from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def assets():
+    g = H.gmm_fixture()
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    return BodyModel.synthetic(0), prior
+
+
+def _mean_params(d):
+    pose = torch.tensor(np.concatenate([d["init_global_orient"][:1], d["init_body_pose"][:1]], axis=1))
+    return pose, torch.tensor(d["init_betas"][:1])
+
+
+def test_optimize_params_frame_matches_reference_golden(assets):
+    model, prior = assets
+    d = H.load_case("amass_noisy_conf")       # mean-pose init, per-joint confidences, noisy targets
+    for f in (0, 3):
+        joints = np.concatenate([d["j3d"][f], d["conf"][:, None]], axis=1)          # (22,4): 4th channel = conf
+        cfg = FrameOptimizeConfig(use_lbfgs=False, num_iters_first=100)
+        res = k2b.optimize_params_frame(joints, joint_layout="AMASS", model=model, config=cfg, pose_prior=prior,
+                                        mean_params=_mean_params(d))
+        assert cfg.joints_category == "AMASS"                                       # config is mutated, as in the reference
+        assert isinstance(res, k2b.BodyModelFitResult) and isinstance(res.params, k2b.SMPLData)
+        assert tuple(res.vertices.shape) == (1, 6890, 3) and tuple(res.joints.shape) == (1, 45, 3)
+        for key in ("global_orient", "body_pose", "betas", "transl"):
+            assert np.abs(getattr(res.params, key).cpu().numpy() - d["out_" + key][f:f + 1]).max() < TOL, key
+        np.testing.assert_allclose(float(res.loss), float(d["out_loss"][f]), rtol=1e-5)
+        assert np.abs(res.joints.cpu().numpy() - d["out_joints"][f:f + 1]).max() < TOL
+
+
+def test_api_error_conventions(assets):
+    model, prior = assets
+    j = np.zeros((22, 3), np.float32)
+    kw = dict(model=model, pose_prior=prior, mean_params=(torch.zeros(1, 72), torch.zeros(1, 10)))
+    with pytest.raises(NotImplementedError):       # reference default is LBFGS: not built on the HIP engine
+        k2b.optimize_params_frame(j, joint_layout="AMASS", **kw)
+    with pytest.raises(NotImplementedError):
+        k2b.optimize_params_frame(j, config={"input_type": "joints2d"}, **kw)
+    with pytest.raises(ValueError):
+        k2b.optimize_params_frame(j, body_model="nope", **kw)
+    with pytest.raises(ValueError):
+        k2b.optimize_params_frame(np.zeros((23, 3), np.float32), config={"use_lbfgs": False}, **kw)
+    with pytest.raises(ValueError):
+        k2b.optimize_params_frame(j, config={"use_lbfgs": False}, prev_params=k2b.MANOData(
+            betas=torch.zeros(1, 10), global_orient=torch.zeros(1, 3), body_pose=torch.zeros(1, 0)), **kw)
+    with pytest.raises(NotImplementedError):
+        k2b.optimize_params_sequence(np.zeros((2, 22, 3), np.float32),
+                                     config={"frame": {"use_lbfgs": False}}, **kw)   # shape pre-pass not built
+
+
+def _oracle_fit(d, rows, init, iters, seq_ind):
+    from oracle.fit_torch import fit_world_adam
+    t = lambda a: torch.tensor(np.asarray(a))
+    return fit_world_adam(H.oracle_model(), H.oracle_prior(), init["go"], init["bp"], init["be"], init["tr"],
+                          t(d["j3d"][rows]), t(d["conf"]), num_iters=iters, seq_ind=seq_ind)
+
+
+def test_sequence_independent_frames_match_oracle(assets):
+    model, prior = assets
+    d = H.load_case("amass_noisy_conf")
+    T = 5
+    seq = np.concatenate([d["j3d"][:T], np.broadcast_to(d["conf"], (T, 22))[..., None]], axis=2)
+    cfg = SequenceOptimizeConfig(frame=FrameOptimizeConfig(use_lbfgs=False, num_iters_first=40, num_iters_followup=15),
+                                 use_shape_optimization=False, use_previous_frame_init=False)
+    res = k2b.optimize_params_sequence(seq, joint_layout="AMASS", model=model, config=cfg, pose_prior=prior,
+                                       mean_params=_mean_params(d))
+    assert len(res) == T
+    mp, ms = _mean_params(d)
+    from oracle.fit_torch import guess_init_transl
+    tr0 = guess_init_transl(H.oracle_model(), mp, ms, torch.tensor(d["j3d"][:1]))
+    init1 = dict(go=mp[:, :3], bp=mp[:, 3:], be=ms, tr=tr0)
+    ref0 = _oracle_fit(d, slice(0, 1), init1, 40, 0)
+    rep = {k: v.expand(T - 1, -1).contiguous() for k, v in init1.items()}
+    refn = _oracle_fit(d, slice(1, T), rep, 15, 1)
+    for i in range(T):
+        ref = ref0 if i == 0 else refn
+        r = 0 if i == 0 else i - 1
+        for key in ("global_orient", "body_pose", "betas", "transl"):
+            got = getattr(res[i].params, key).cpu()
+            assert (got - getattr(ref, key)[r:r + 1]).abs().max() < TOL, (i, key)
+        assert abs(float(res[i].loss) - float(ref.loss[r])) / float(ref.loss[r]) < 1e-5
+
+
+def test_sequence_warm_start_chain_matches_oracle(assets):
+    model, prior = assets
+    d = H.load_case("amass_noisy_conf")
+    T = 3
+    seq = d["j3d"][:T]
+    cfg = {"frame": {"use_lbfgs": False, "num_iters_first": 30, "num_iters_followup": 10},
+           "use_shape_optimization": False, "fix_foot": True}
+    res = k2b.optimize_params_sequence(seq, model=model, config=cfg, pose_prior=prior, mean_params=_mean_params(d))
+    assert len(res) == T
+    from oracle.fit_torch import fit_world_adam, guess_init_transl
+    mp, ms = _mean_params(d)
+    conf = torch.ones(22); conf[[7, 8, 10, 11]] = 1.5
+    prev = dict(go=mp[:, :3], bp=mp[:, 3:], be=ms, tr=guess_init_transl(H.oracle_model(), mp, ms, torch.tensor(seq[:1])))
+    for i in range(T):
+        o = fit_world_adam(H.oracle_model(), H.oracle_prior(), prev["go"], prev["bp"], prev["be"], prev["tr"],
+                           torch.tensor(seq[i:i + 1]), conf, num_iters=30 if i == 0 else 10, seq_ind=i)
+        for key, ok in (("global_orient", o.global_orient), ("body_pose", o.body_pose), ("betas", o.betas),
+                        ("transl", o.transl)):
+            assert (getattr(res[i].params, key).cpu() - ok).abs().max() < TOL, (i, key)
+        prev = dict(go=o.global_orient, bp=o.body_pose, be=o.betas, tr=o.transl)
+    last = k2b.optimize_shape_sequence(seq, model=model, config=cfg, pose_prior=prior, mean_params=_mean_params(d))
+    assert torch.equal(last.body_pose, res[-1].params.body_pose)
