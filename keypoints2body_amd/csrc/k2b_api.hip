@@ -148,7 +148,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
     // LBS operands: B side of the two GEMMs, f16 hi/lo in fragment order (k2b_lbs.hip)
     {
         const int P = m->P;
-        const int KX = (P + NB + 2 + 15) / 16, KA = (J + 15) / 16;
+        const int KX = ((P + NB + 2 + 31) / 32) * 2, KA = (J + 15) / 16;   // even: the kernel stages 32-deep slices
         m->k_steps_x = KX;
         m->k_steps_a = KA;
         auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids) -> int {
@@ -162,7 +162,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                 const int v = ids[i];
                 for (int c = 0; c < 3; ++c) {
                     auto put = [&](int k, k2b::k2b_half hi, k2b::k2b_half lo) {
-                        const size_t o = ((((size_t)(k >> 4) * 3 + c) * vp + i) * 16) + (k & 15);
+                        const size_t o = k2b::frag_elem(((size_t)(k >> 4) * 3 + c) * vs.v_tiles + (i >> 5), k, i);
                         pdh[o] = hi;
                         pdl[o] = lo;
                     };
@@ -183,7 +183,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                 for (int j = 0; j < J; ++j) {
                     const float w = lbs_weights[(size_t)v * J + j];
                     const k2b::k2b_half hi = (k2b::k2b_half)w;
-                    const size_t o = (((size_t)(j >> 4) * vp + i) * 16) + (j & 15);
+                    const size_t o = k2b::frag_elem((size_t)(j >> 4) * vs.v_tiles + (i >> 5), j, i);
                     wth[o] = hi;
                     wtl[o] = (k2b::k2b_half)(w - (float)hi);
                 }

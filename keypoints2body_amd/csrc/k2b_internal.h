@@ -57,6 +57,13 @@ hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);
 typedef _Float16 k2b_half;
 constexpr float kPdScale = 256.0f;   // power-of-two scale of the vertex-GEMM B operand (keeps f16 lo terms normal)
 
+// Element (k, row) inside fragment number `frag` of a fragment-ordered operand: a fragment is the
+// 1 KiB a wave consumes for one 16-deep k-step of one 32-row tile, stored lane-linear:
+// [h = (k >> 3) & 1][row & 31][k & 7]  (lane 32 h + row owns 16 contiguous bytes).
+__host__ __device__ inline size_t frag_elem(size_t frag, int k, int row) {
+    return ((frag * 2 + ((k >> 3) & 1)) * 32 + (row & 31)) * 8 + (k & 7);
+}
+
 // Pose set-up for LBS: per frame the relative transforms A_j (3x4) and the feature vector
 // X = [vec(R_1..R_{J-1} - I) | beta | 1 | 1] as f16 hi/lo MFMA operands, plus the posed
 // kinematic joints (+ transl).
@@ -68,8 +75,8 @@ struct PoseArgs {
     int num_frames, frames_padded;
     int k_steps_x, k_steps_a;  // 16-deep k-steps of the vertex GEMM (features) and of the transform GEMM (joints)
     const float *go, *bp, *be, *tr;  // tr may be null
-    k2b_half *xh, *xl;         // [k_steps_x][frames_padded][16]
-    k2b_half *ah, *al;         // [12][k_steps_a][frames_padded][16]
+    k2b_half *xh, *xl;         // fragments [k_steps_x][frames_padded / 32]
+    k2b_half *ah, *al;         // fragments [12][k_steps_a][frames_padded / 32]
     float* joints_out;         // [B][num_out_joints][3] (first J rows written) or null
 };
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream);
@@ -77,8 +84,8 @@ int lbs_frames_padded(int num_frames);
 
 // One vertex set (the whole mesh, or the E vertex-selected joints) as B operands.
 struct SkinArgs {
-    const k2b_half *pdh, *pdl;   // [k_steps_x][3][v_tiles*32][16]  (posedirs ; shapedirs ; template ; residual) * kPdScale
-    const k2b_half *wth, *wtl;   // [k_steps_a][v_tiles*32][16]     skinning weights, k = joint
+    const k2b_half *pdh, *pdl;   // fragments [k_steps_x][3][v_tiles]  (posedirs ; shapedirs ; template ; residual) * kPdScale
+    const k2b_half *wth, *wtl;   // fragments [k_steps_a][v_tiles]     skinning weights, k = joint
     int v_tiles, num_out;        // 32-vertex tiles, real vertex count of the set
     int k_steps_x, k_steps_a;
     int num_frames, frames_padded, f_tiles;

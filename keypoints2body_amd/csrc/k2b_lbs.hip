@@ -16,11 +16,13 @@
 // v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): 3/16 of the fp32 MFMA time
 // at fp32-level accuracy (|error| ~ 1e-6 m on metre-scale vertices; tests/test_gpu_parity.py).
 //
-// Tiling: one wave owns a 32-frame x 32-vertex tile.  MFMA orientation D[frame][vertex]: the
-// accumulator of lane l holds 16 frames of ONE vertex (column l & 31), so the skinning epilogue
-// (T applied to v_posed) is a per-lane computation with no cross-lane traffic.  Operand
-// fragments are stored k-step-major ([ks][row][16 halfs]) so that a wave's fragment load is one
-// contiguous 1 KiB read.
+// Tiling: a workgroup of 8 waves owns 128 frames x 64 vertices; each wave a 32 x 32 sub-tile.
+// MFMA orientation D[frame][vertex]: the accumulator of lane l holds 16 frames of ONE vertex
+// (column l & 31), so the skinning epilogue (T applied to v_posed) is a per-lane computation with
+// no cross-lane traffic.  Operands are stored as 1 KiB "fragments" in exactly the order the 64
+// lanes of a wave consume them ([k-step][32-row tile][k-half h][row][8 halfs]: lane 32 h + row
+// owns 16 contiguous bytes), so a fragment moves global -> LDS as one linear 1 KiB copy and is
+// read back with conflict-free ds_read_b128.
 #include <hip/hip_fp16.h>
 
 #include "k2b_internal.h"
@@ -29,6 +31,13 @@ namespace k2b {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// Fragment number of transform entry `entry` (0..11 = 4 r + e), k-step ks, frame tile `tile`:
+// [entry >> 1][ks][entry & 1][tile]: the six entry pairs are consecutive slices a constant stride
+// apart, each holding both entries of the pair for every joint k-step.
+__device__ __forceinline__ size_t a_frag(int entry, int ks, int k_steps, int tiles, int tile) {
+    return ((size_t)((entry >> 1) * k_steps + ks) * 2 + (entry & 1)) * tiles + tile;
+}
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -78,11 +87,11 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     }
     __syncthreads();
 
-    // X operand of the vertex GEMM, f16 hi/lo, fragment layout [ks][frame][16]
+    // X operand of the vertex GEMM, f16 hi/lo, fragments [ks][frame tile]
     auto put_x = [&](int k, float x) {
         _Float16 hi, lo;
         split_f16(x, hi, lo);
-        const size_t o = ((size_t)(k >> 4) * bp + f) * 16 + (k & 15);
+        const size_t o = frag_elem((size_t)(k >> 4) * (bp >> 5) + (f >> 5), k, f);
         a.xh[o] = hi;
         a.xl[o] = lo;
     };
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     // zero rows of the A operand for the padded joints J .. 16*k_steps_a - 1
     for (int idx = j; idx < (a.k_steps_a * 16 - J) * 12; idx += 64) {
         const int jj = J + idx / 12, e = idx % 12;
-        const size_t o = (((size_t)e * a.k_steps_a + (jj >> 4)) * bp + f) * 16 + (jj & 15);
+        const size_t o = frag_elem(a_frag(e, jj >> 4, a.k_steps_a, bp >> 5, f >> 5), jj, f);
         a.ah[o] = (_Float16)0.f;
         a.al[o] = (_Float16)0.f;
     }
@@ -113,14 +122,14 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         pg = mul(Ra, pg) + da;
         Rg = mul(Ra, Rg);
     }
-    // A_j = [Rg | pg - Rg J_j], f16 hi/lo, fragment layout [e][ks][frame][16] with k = joint
+    // A_j = [Rg | pg - Rg J_j], f16 hi/lo, fragments [entry pair][ks][entry & 1][frame tile], k = joint
     const Vec3 rj = mul(Rg, Jj);
     const float At[12] = {Rg.m[0], Rg.m[1], Rg.m[2], pg.x - rj.x, Rg.m[3], Rg.m[4], Rg.m[5], pg.y - rj.y,
                           Rg.m[6], Rg.m[7], Rg.m[8], pg.z - rj.z};
     for (int e = 0; e < 12; ++e) {
         _Float16 hi, lo;
         split_f16(At[e], hi, lo);
-        const size_t o = (((size_t)e * a.k_steps_a + (j >> 4)) * bp + f) * 16 + (j & 15);
+        const size_t o = frag_elem(a_frag(e, j >> 4, a.k_steps_a, bp >> 5, f >> 5), j, f);
         a.ah[o] = hi;
         a.al[o] = lo;
     }
@@ -133,76 +142,125 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Vertex kernel: one wave per (32 frames x 32 vertices) tile, 4 waves per workgroup.
+// Vertex kernel: workgroup = 8 waves = 4 frame tiles x 2 vertex tiles (128 frames x 64 vertices).
+//
+// Slices staged through LDS (ring of 3 slots), one barrier per slice, exactly 5 (pose) or 4
+// (transform) fragments loaded per wave and slice from precomputed pointers that advance by a
+// constant stride - the per-slice bookkeeping is a handful of scalar adds:
+//   pose slice  s (32-deep: k-steps 2s, 2s+1): 16 X + 24 Pd fragments, 18 MFMAs per wave
+//   transform slice t = entry pair (6)       : 32 A fragments (2 entries x 2 joint k-steps), 12 MFMAs per wave
+// The skinning-weight fragments (KA x 2 tiles x hi/lo) are loaded once and stay resident.
 // ---------------------------------------------------------------------------------------------
-constexpr int kChunkPairs = 8;   // frame-tile pairs (64 frames each) per L2-resident chunk
+constexpr int kChunkGroups = 4;      // frame groups (128 frames each) per L2-resident chunk
+constexpr int kFragHalfs = 512;      // one fragment = 64 lanes x 8 halfs = 1 KiB
+constexpr int kSlotFrags = 40;       // fragments per ring slot
+constexpr int kMaxKA = 4;            // joints <= 64
 
-__device__ __forceinline__ half8 ld_frag(const _Float16* base, size_t row_index, int h) {
-    return *reinterpret_cast<const half8*>(base + row_index * 16 + 8 * h);
-}
+__global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 ring[3][kSlotFrags][kFragHalfs];   // 120 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 wres[kMaxKA * 4][kFragHalfs];      // <= 16 KiB
 
-__global__ __launch_bounds__(256, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int col = lane & 31, h = lane >> 5;
-    // workgroup = 2 frame tiles x 2 vertex tiles.  Rasterisation for the 8 per-XCD L2s (blocks are
-    // dealt round-robin over the XCDs, so b % 8 labels blocks that share an L2): each label owns
-    // every 8th vertex-tile pair, and inside a chunk of kChunkPairs frame-tile pairs the frame
-    // index runs fastest - the 172 KB of vertex operands of one pair stay L2-resident while the
-    // chunk's frames sweep over them, and the chunk's per-frame operands (1.2 MB) stay resident
-    // while the vertex pairs advance.  Placement affects speed only.
-    const int vpairs = (a.v_tiles + 1) / 2, fpairs = (a.f_tiles + 1) / 2;
-    const int vl = (vpairs + 7) / 8;                       // vertex-tile pairs per label
-    const int label = blockIdx.x & 7, i = blockIdx.x >> 3;
-    const int chunk = i / (vl * kChunkPairs), rem = i % (vl * kChunkPairs);
-    const int vpair = (rem / kChunkPairs) * 8 + label, fpair = chunk * kChunkPairs + rem % kChunkPairs;
-    if (vpair >= vpairs || fpair >= fpairs) return;
-    const int vt = vpair * 2 + (wave & 1);
-    const int ft = fpair * 2 + (wave >> 1);
-    if (vt >= a.v_tiles || ft >= a.f_tiles) return;
-    const int vp = a.v_tiles * 32;          // padded vertex count of this vertex set
-    const int bp = a.frames_padded;
-    const int KS = a.k_steps_x, KA = a.k_steps_a;
-    const size_t frow = (size_t)ft * 32 + col;      // A-operand row (frame) of this lane
-    const size_t vrow = (size_t)vt * 32 + col;      // B-operand column (vertex) of this lane
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar addressing
+    const int ftl = wave >> 1, vtl = wave & 1;      // this wave's sub-tile inside the workgroup tile
+    const int h = lane >> 5, col = lane & 31;
 
-    // ---- 1. v_posed * 256 = X . Pd  (three coordinates) -------------------------------------------
+    // Rasterisation for the 8 per-XCD L2s (blocks are dealt round-robin over the XCDs, so b % 8
+    // labels blocks that share an L2): each label owns every 8th vertex group, and inside a chunk
+    // of kChunkGroups frame groups the frame index runs fastest - the vertex operands of one group
+    // (172 KB) stay L2-resident while the chunk's frames sweep over them, and the chunk's per-frame
+    // operands (1.2 MB) stay resident while the vertex groups advance.  Placement affects speed only.
+    const int vgroups = (a.v_tiles + 1) / 2, fgroups = (a.f_tiles + 3) / 4;
+    const int vl = (vgroups + 7) / 8;
+    const int label = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int chunk = bi / (vl * kChunkGroups), rem = bi % (vl * kChunkGroups);
+    const int vg = (rem / kChunkGroups) * 8 + label, fg = chunk * kChunkGroups + rem % kChunkGroups;
+    if (vg >= vgroups || fg >= fgroups) return;     // whole workgroup leaves together
+    const int ftiles = a.f_tiles, vtiles = a.v_tiles;
+    const int KS2 = a.k_steps_x / 2, KA = a.k_steps_a;   // k_steps_x is even (k2b_model_create)
+    // tiles past the end are clamped for loading (their results are never stored)
+    auto ftile = [&](int t) { const int x = fg * 4 + t; return x < ftiles ? x : ftiles - 1; };
+    auto vtile = [&](int t) { const int x = vg * 2 + t; return x < vtiles ? x : vtiles - 1; };
+
+    // ---- source pointers of this wave's fragment slots (q = wave + 8 i), computed once -------------
+    const _Float16* psrc[5];     // pose slices
+    size_t pstride[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int q = wave + 8 * i;
+        if (q < 16) {            // X: [ksl][ft][hl]
+            const int ksl = q >> 3, ft = (q >> 1) & 3;
+            psrc[i] = ((q & 1) ? a.xl : a.xh) + ((size_t)ksl * ftiles + ftile(ft)) * kFragHalfs + lane * 8;
+            pstride[i] = (size_t)2 * ftiles * kFragHalfs;
+        } else {                 // Pd: [ksl][vt][c][hl]
+            const int i2 = q - 16, ksl = i2 / 12, r12 = i2 % 12, vt = r12 / 6, c = (r12 % 6) >> 1;
+            psrc[i] = ((i2 & 1) ? a.pdl : a.pdh) + (((size_t)ksl * 3 + c) * vtiles + vtile(vt)) * kFragHalfs + lane * 8;
+            pstride[i] = (size_t)2 * 3 * vtiles * kFragHalfs;
+        }
+    }
+    const _Float16* asrc[4];     // transform slices: A [ft][ks][e2][hl]   (KA == 2: checked by the launcher)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave + 8 * i, ft = q >> 3, kse = (q >> 1) & 3;
+        asrc[i] = ((q & 1) ? a.al : a.ah) + ((size_t)kse * ftiles + ftile(ft)) * kFragHalfs + lane * 8;
+    }
+    const size_t astride = (size_t)4 * ftiles * kFragHalfs;
+
+    // ---- resident skinning weights: fragment (ks, vt, hl) -> wres[(ks * 2 + vt) * 2 + hl] ------------
+    for (int q = wave; q < KA * 4; q += 8) {
+        const int ks = q >> 2, vt = (q >> 1) & 1;
+        const _Float16* src = ((q & 1) ? a.wtl : a.wth) + ((size_t)ks * vtiles + vtile(vt)) * kFragHalfs + lane * 8;
+        *reinterpret_cast<half8*>(&wres[q][lane * 8]) = *reinterpret_cast<const half8*>(src);
+    }
+
+    half8 stage[5];
+    auto load_pose = [&]() {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { stage[i] = *reinterpret_cast<const half8*>(psrc[i]); psrc[i] += pstride[i]; }
+    };
+    auto load_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { stage[i] = *reinterpret_cast<const half8*>(asrc[i]); asrc[i] += astride; }
+    };
+    auto commit = [&](int slot, int n) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (i < n) *reinterpret_cast<half8*>(&ring[slot][wave + 8 * i][lane * 8]) = stage[i];
+    };
+    auto frag = [&](int slot, int q) -> half8 { return *reinterpret_cast<const half8*>(&ring[slot][q][lane * 8]); };
+
     floatx16 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
-    {
-        half8 xh = ld_frag(a.xh, frow, h), xl = ld_frag(a.xl, frow, h);
-        half8 ph[3], pl[3];
+
+    const int nslices = KS2 + 6;
+    load_pose();
+    commit(0, 5);
+    __syncthreads();
+
+    // ---- phase 1: v_posed * kPdScale = X . Pd for the three coordinates -----------------------------
+    for (int s = 0; s < KS2; ++s) {
+        const int slot = s % 3, nslot = (s + 1) % 3;
+        const bool next_pose = s + 1 < KS2;
+        if (next_pose) load_pose(); else load_a();
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the slice: its latency hides under the MFMAs
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            ph[c] = ld_frag(a.pdh, (size_t)c * vp + vrow, h);
-            pl[c] = ld_frag(a.pdl, (size_t)c * vp + vrow, h);
-        }
-        for (int ks = 0; ks < KS; ++ks) {
-            half8 nxh = xh, nxl = xl, nph[3], npl[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { nph[c] = ph[c]; npl[c] = pl[c]; }
-            if (ks + 1 < KS) {
-                nxh = ld_frag(a.xh, (size_t)(ks + 1) * bp + frow, h);
-                nxl = ld_frag(a.xl, (size_t)(ks + 1) * bp + frow, h);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    nph[c] = ld_frag(a.pdh, ((size_t)(ks + 1) * 3 + c) * vp + vrow, h);
-                    npl[c] = ld_frag(a.pdl, ((size_t)(ks + 1) * 3 + c) * vp + vrow, h);
-                }
-            }
+        for (int ksl = 0; ksl < 2; ++ksl) {
+            const half8 xh = frag(slot, ksl * 8 + ftl * 2), xl = frag(slot, ksl * 8 + ftl * 2 + 1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, ph[c], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, pl[c], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, ph[c], acc[c], 0, 0, 0);
+                const int q = 16 + ksl * 12 + vtl * 6 + c * 2;
+                const half8 ph = frag(slot, q), pl = frag(slot, q + 1);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, ph, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, pl, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, ph, acc[c], 0, 0, 0);
             }
-            xh = nxh; xl = nxl;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { ph[c] = nph[c]; pl[c] = npl[c]; }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        commit(nslot, next_pose ? 5 : 4);
+        __syncthreads();
     }
     const float inv_scale = 1.0f / kPdScale;
 #pragma unroll
@@ -210,35 +268,64 @@ __global__ __launch_bounds__(256, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] *= inv_scale;
 
-    // ---- 2. per output coordinate r: T[4r..4r+3] = A . W^T, then out_r = T . [v_posed; 1] -----------
-    const int v = vt * 32 + col;                       // index inside this vertex set
-    const bool v_ok = v < a.num_out;
-#pragma unroll 1
+    // ---- phase 2: out_r = T[4r..4r+3] . [v_posed; 1] + transl, T = A . W^T ----------------------------
+    // One slice per entry pair (T[4r], T[4r+1]) / (T[4r+2], T[4r+3]): two 32x32 accumulators live.
+    const int ft = fg * 4 + ftl, vt = vg * 2 + vtl;
+    const int v = vt * 32 + col;
+    const bool store_ok = ft < ftiles && vt < vtiles && v < a.num_out;
+    // frame of accumulator register i (C/D map of 32x32 MFMA: column = lane & 31,
+    // row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)), clamped for the translation prefetch
+    const int frow0 = ft * 32 + 4 * h;
+    const int flast = a.num_frames - 1;
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
-        floatx16 t4[4];
+        float outp[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) t4[e][i] = 0.f;
-        for (int ks = 0; ks < KA; ++ks) {
-            const half8 wh = ld_frag(a.wth, (size_t)ks * vp + vrow, h), wl = ld_frag(a.wtl, (size_t)ks * vp + vrow, h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const size_t row = ((size_t)(4 * r + e) * KA + ks) * bp + frow;
-                const half8 ah = ld_frag(a.ah, row, h), al = ld_frag(a.al, row, h);
-                t4[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, t4[e], 0, 0, 0);
-                t4[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, t4[e], 0, 0, 0);
-                t4[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, t4[e], 0, 0, 0);
-            }
+        for (int i = 0; i < 16; ++i) {      // start from the translation of the frame this register holds
+            const int f = frow0 + (i & 3) + 8 * (i >> 2);
+            outp[i] = a.tr ? a.tr[(size_t)(f < flast ? f : flast) * 3 + r] : 0.f;
         }
-        // C/D map of 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int f = ft * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (v_ok && f < a.num_frames) {
-                float o = t4[0][i] * acc[0][i] + t4[1][i] * acc[1][i] + t4[2][i] * acc[2][i] + t4[3][i];
-                if (a.tr) o += a.tr[(size_t)f * 3 + r];
-                a.out[((size_t)f * a.out_stride + a.out_row0 + v) * 3 + r] = o;
+        for (int half = 0; half < 2; ++half) {
+            const int s = KS2 + 2 * r + half, slot = s % 3, nslot = (s + 1) % 3;
+            const bool more = s + 1 < nslices;
+            if (more) load_a();
+            __builtin_amdgcn_sched_barrier(0);
+            floatx16 t2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t2[e][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 wh = *reinterpret_cast<const half8*>(&wres[(ks * 2 + vtl) * 2][lane * 8]);
+                const half8 wl = *reinterpret_cast<const half8*>(&wres[(ks * 2 + vtl) * 2 + 1][lane * 8]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const half8 ah = frag(slot, ftl * 8 + ks * 4 + e * 2), al = frag(slot, ftl * 8 + ks * 4 + e * 2 + 1);
+                    t2[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, t2[e], 0, 0, 0);
+                    t2[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, t2[e], 0, 0, 0);
+                    t2[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, t2[e], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) commit(nslot, 4);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                outp[i] += half == 0 ? t2[0][i] * acc[0][i] + t2[1][i] * acc[1][i] : t2[0][i] * acc[2][i] + t2[1][i];
+        }
+        if (store_ok) {
+            float* orow = a.out + ((size_t)a.out_row0 + v) * 3 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int f = frow0 + (i & 3) + 8 * (i >> 2);
+#ifdef K2B_LBS_NOSTORE   // timing-only diagnostic build: keep the value live, drop the store
+                asm volatile("" ::"v"(outp[i]));
+                (void)orow;
+#else
+                if (f <= flast) orow[(size_t)f * a.out_stride * 3] = outp[i];
+#endif
             }
         }
     }
@@ -265,10 +352,10 @@ hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream) {
 
 hipError_t launch_skin(const SkinArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0 || a.num_out <= 0) return hipSuccess;
-    const int vpairs = (a.v_tiles + 1) / 2, fpairs = (a.f_tiles + 1) / 2;
-    const int vl = (vpairs + 7) / 8, chunks = (fpairs + kChunkPairs - 1) / kChunkPairs;
-    const dim3 grid(8 * vl * kChunkPairs * chunks);
-    hipLaunchKernelGGL(k2b_lbs_mfma_kernel, grid, dim3(256), 0, stream, a);
+    if (a.k_steps_a != 2 || (a.k_steps_x & 1)) return hipErrorInvalidValue;   // 17..32 joints (SMPL: 24)
+    const int vgroups = (a.v_tiles + 1) / 2, fgroups = (a.f_tiles + 3) / 4;
+    const int vl = (vgroups + 7) / 8, chunks = (fgroups + kChunkGroups - 1) / kChunkGroups;
+    hipLaunchKernelGGL(k2b_lbs_mfma_kernel, dim3(8 * vl * kChunkGroups * chunks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
