@@ -20,6 +20,15 @@
 //                  LDS allocation.
 // The two layouts exchange values through a 96-float wave-private LDS staging strip.
 //
+// Two execution shapes (template parameter SPLIT):
+//   unified  one wave does everything for its frame (large batches: >= 2 waves per SIMD hide latency);
+//   split    small batches (<= 4 frames per CU) leave SIMDs idle, so each frame gets TWO waves that
+//            run concurrently on different SIMDs: the "row" wave (GMM prior + Adam, owns the
+//            optimiser state) and the "tree" wave (kinematics, joint loss, analytic backward).
+//            The two parts of an iteration are independent given the parameters, so the critical
+//            path is max(GMM, tree) instead of their sum; they meet at two workgroup barriers per
+//            iteration and exchange parameters / gradients through the LDS strips.
+//
 // Latency, not throughput, bounds this kernel at one wave per SIMD (1024 frames on 1024
 // SIMDs), so every phase is written to keep many independent LDS operations in flight:
 // the GMM matrix-vector products are software-pipelined by hand (sched_barrier pins the
@@ -125,7 +134,7 @@ __device__ __forceinline__ float butterfly16_sum(const float (&v)[16], int lane)
 
 }  // namespace
 
-template <int NBT>
+template <int NBT, bool SPLIT>
 __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[P_FLOATS + MAXW * XS];
 
@@ -143,10 +152,20 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     }
     __syncthreads();
 
-    const int f = blockIdx.x * waves + wave;   // frame of this wave
-    if (f >= a.num_frames) return;             // no further workgroup-wide sync below
+    // frame and role of this wave
+    const int frames_per_wg = SPLIT ? waves >> 1 : waves;
+    const int fslot = SPLIT ? wave >> 1 : wave;
+    const bool do_row = !SPLIT || (wave & 1) == 0;    // GMM prior, priors in row layout, Adam, results
+    const bool do_tree = !SPLIT || (wave & 1) == 1;   // kinematics, joint loss, analytic backward
+    const int f_raw = blockIdx.x * frames_per_wg + fslot;
+    if (!SPLIT && f_raw >= a.num_frames) return;      // unified: no further workgroup-wide sync below
+    // split: waves of a padding slot must still reach every barrier; they recompute the last frame
+    // and skip the final stores
+    const bool f_valid = f_raw < a.num_frames;
+    const int f = f_valid ? f_raw : a.num_frames - 1;
 
-    float* xs = lds + P_FLOATS + wave * XS;
+    float* xs = lds + P_FLOATS + (SPLIT ? 2 * fslot : wave) * XS;     // parameters, row wave -> tree wave
+    float* gs = SPLIT ? xs + XS : xs;                                  // gradients, tree wave -> row wave
     const float4* pa4 = reinterpret_cast<const float4*>(lds);  // [m][17][64] float4
     const float* pa68 = lds + MG * 17 * 256;                   // [m][64]
     const float* pbl = lds + PA_FLOATS;                        // [m][9][64]
@@ -193,12 +212,17 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         anc_ok[r] = lt[2 + r] >= 0;
         anc_addr[r] = (anc_ok[r] ? lt[2 + r] : lane) * 4;
     }
-    int win_addr[kMaxWinBits];
-    bool win_ok[kMaxWinBits];
+    // the same windows for the upper half-wave (lane 32 + t mirrors lane t, sources shifted by 32 lanes)
+    int win_addr_h[kMaxWinBits];
+    bool win_ok_h[kMaxWinBits];
+    {
+        const int* lt2 = a.lane_tab + (lane & 31) * kLaneTabStride;
 #pragma unroll
-    for (int b = 0; b < kMaxWinBits; ++b) {
-        win_ok[b] = lt[2 + kMaxRounds + b] >= 0;
-        win_addr[b] = (win_ok[b] ? lt[2 + kMaxRounds + b] : lane) * 4;
+        for (int b = 0; b < kMaxWinBits; ++b) {
+            const int src = lt2[2 + kMaxRounds + b];
+            win_ok_h[b] = src >= 0;
+            win_addr_h[b] = (src >= 0 ? src + (lane & 32) : lane) * 4;
+        }
     }
     float dt[3], dd[3][NBT];
 #pragma unroll
@@ -253,11 +277,15 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 #endif
         K2B_STAMP(0);
         // ---- a. parameters -> staging strip ------------------------------------------------
-        xs[offA] = x0;
-        if (actB) xs[offB] = x1;
-        wave_sync();
+        if (do_row) {
+            xs[offA] = x0;
+            if (actB) xs[offB] = x1;
+        }
+        if (SPLIT) __syncthreads(); else wave_sync();
 
         K2B_STAMP(1);
+        float yA = 0.f, yBs = 0.f, best = 0.f;
+        if (do_row) {
         // ---- c. GMM prior: y_m = P_m theta - P_m mu_m for every component ----------------------
         // rows 0..60 (set A).  Hand-pipelined: block jb+1's nine ds_read_b128 are in flight
         // while block jb's 32 FMAs issue.
@@ -335,19 +363,21 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         q += __shfl_xor(q, 2, kWave);
         q += __shfl_xor(q, 1, kWave);                        // lanes 8m..8m+7: d^T P d of component m
         const float val = 0.5f * q + a.neg_log_nllw[sB < M ? sB : 0];
-        float best = read_lane(val, 0);
+        best = read_lane(val, 0);
         int mstar = 0;
 #pragma unroll
         for (int m = 1; m < MG; ++m) {
             const float vm = read_lane(val, 8 * m);
             if (m < M && vm < best) { best = vm; mstar = m; }
         }
-        float yA = acc[0];
+        yA = acc[0];
 #pragma unroll
         for (int m = 1; m < MG; ++m) yA = (mstar == m) ? acc[m] : yA;
-        const float yBs = bperm((rB + 8 * mstar) * 4, yB);   // row 61+lane for lanes < 8
+        yBs = bperm((rB + 8 * mstar) * 4, yB);   // row 61+lane for lanes < 8
+        }  // do_row: GMM
 
         K2B_STAMP(4);
+        if (do_tree) {
         // ---- b/d. tree-layout reads, J(beta), Rodrigues ---------------------------------------------
         const Vec3 th = {xs[thoff], xs[thoff + 1], xs[thoff + 2]};
         const Vec3 tr = {xs[XS_TRANSL], xs[XS_TRANSL + 1], xs[XS_TRANSL + 2]};
@@ -394,43 +424,64 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         K2B_STAMP(6);
         // ---- e. joint loss, its gradient, subtree force / torque sums ------------------------------
         Vec3 gj = {0.f, 0.f, 0.f};
-        float part = 0.f;                  // per-lane partial of the loss (summed at the end)
+        float part = 0.f;                  // per-lane partial of the joint loss
         if (tk >= 0) {
             const float ex = pj.x + tr.x - tgt.x, ey = pj.y + tr.y - tgt.y, ez = pj.z + tr.z - tgt.z;
             const float x2 = ex * ex, y2 = ey * ey, z2 = ez * ez;
             const float dx = s2 + x2, dy = s2 + y2, dz = s2 + z2;
             if (last) part = wconf * ((s2 * x2) / dx + (s2 * y2) / dy + (s2 * z2) / dz);
-            gj = {wconf * 2.f * ex * (s2 * s2) / (dx * dx), wconf * 2.f * ey * (s2 * s2) / (dy * dy),
-                  wconf * 2.f * ez * (s2 * s2) / (dz * dz)};
+            // d gmof / d e = 2 e s^4 / (s^2 + e^2)^2
+            const float k2 = 2.f * wconf * (s2 * s2);
+            gj = {k2 * ex / (dx * dx), k2 * ey / (dy * dy), k2 * ez / (dz * dz)};
         }
         K2B_STAMP(7);
         // subtree sums of g and p x g: a subtree is the lane range [t, t + size_t), summed as
-        // power-of-two windows W_b[x] = sum of lanes x .. x + 2^b - 1
+        // power-of-two windows W_b[x] = sum of lanes x .. x + 2^b - 1.  The two triples ride in the
+        // two 32-lane halves (g in lanes t, p x g in lanes 32 + t), so one cross-lane move serves both.
         float sums[6];
         {
             const Vec3 pxg = cross(pj, gj);
-            float wcur[6] = {gj.x, gj.y, gj.z, pxg.x, pxg.y, pxg.z};
+            const bool up_half = lane >= 32;
+            const int mirror = (lane ^ 32) * 4;
+            float w3[3];
+            {
+                const float lo[3] = {isJ ? gj.x : 0.f, isJ ? gj.y : 0.f, isJ ? gj.z : 0.f};
+                const float hi[3] = {isJ ? pxg.x : 0.f, isJ ? pxg.y : 0.f, isJ ? pxg.z : 0.f};
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                wcur[i] = isJ ? wcur[i] : 0.f;
-                const float t = bperm(win_addr[0], wcur[i]);
-                sums[i] = win_ok[0] ? t : 0.f;
+                for (int i = 0; i < 3; ++i) {
+                    const float moved = bperm(mirror, hi[i]);       // lanes 32 + t receive p x g of joint t
+                    w3[i] = up_half ? moved : lo[i];
+                }
+            }
+            const int half_off = up_half ? 128 : 0;                 // byte offset of the upper half's lanes
+            float s3[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float t = bperm(win_addr_h[0], w3[i]);
+                s3[i] = win_ok_h[0] ? t : 0.f;
             }
 #pragma unroll
             for (int b = 1; b < kMaxWinBits; ++b) {
                 if (b < a.num_win_bits) {
                     const int dn = ((lane + (1 << (b - 1))) & 63) * 4;
-                    float up[6];
+                    float up[3];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) up[i] = bperm(dn, wcur[i]);
+                    for (int i = 0; i < 3; ++i) up[i] = bperm(dn, w3[i]);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) wcur[i] += up[i];                  // W_b
+                    for (int i = 0; i < 3; ++i) w3[i] += up[i];                    // W_b
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        const float t = bperm(win_addr[b], wcur[i]);
-                        sums[i] += win_ok[b] ? t : 0.f;
+                    for (int i = 0; i < 3; ++i) {
+                        const float t = bperm(win_addr_h[b], w3[i]);
+                        s3[i] += win_ok_h[b] ? t : 0.f;
                     }
                 }
+            }
+            (void)half_off;
+            // bring the p x g sums back to the joint's own lane
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sums[i] = s3[i];
+                sums[3 + i] = bperm(mirror, s3[i]);
             }
         }
         const Vec3 aj = {sums[0], sums[1], sums[2]};
@@ -459,15 +510,22 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         const Vec3 groot = {read_lane(aj.x, 0), read_lane(aj.y, 0), read_lane(aj.z, 0)};  // root = lane 0: d/d transl
 
         K2B_STAMP(10);
-        // ---- f. tree layout -> row layout, then the priors (already in row layout) -------------------
+        // ---- f. tree layout -> gradient strip (unified: the parameter strip is reused) --------------
+        const float jloss = last ? wave_sum(part) : 0.f;
         wave_sync();
-        if (isJ) { xs[thoff] = gth.x; xs[thoff + 1] = gth.y; xs[thoff + 2] = gth.z; }
-        if ((lane & 3) == 0 && (lane >> 2) < NB) xs[XS_BETA + (lane >> 2)] = gbeta;
-        if (lane == 63) { xs[XS_TRANSL] = groot.x; xs[XS_TRANSL + 1] = groot.y; xs[XS_TRANSL + 2] = groot.z; }
+        if (isJ) { gs[thoff] = gth.x; gs[thoff + 1] = gth.y; gs[thoff + 2] = gth.z; }
+        if ((lane & 3) == 0 && (lane >> 2) < NB) gs[XS_BETA + (lane >> 2)] = gbeta;
+        if (lane == 63) { gs[XS_TRANSL] = groot.x; gs[XS_TRANSL + 1] = groot.y; gs[XS_TRANSL + 2] = groot.z; gs[XS - 1] = jloss; }
+        }  // do_tree
+        if (SPLIT) __syncthreads(); else wave_sync();
+
+        if (do_row) {
+        // ---- row layout: gradients of the joint term, then the priors ---------------------------------
+        g0 = gs[offA];
+        g1 = actB ? gs[offB] : 0.f;
+        const float jloss = gs[XS - 1];
         wave_sync();
-        g0 = xs[offA];
-        g1 = actB ? xs[offB] : 0.f;
-        wave_sync();
+        float part = 0.f;                  // per-lane partial of the prior losses
         if (bodyA) {
             g0 += wpp2 * yA + 2.f * wpr2 * (x0 - pr0);
             if (angA != 0.f) {
@@ -485,7 +543,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             g1 += 2.f * ws2 * x1;
             if (last) part += ws2 * x1 * x1;
         }
-        if (last) loss_total = wave_sum(part) + wpp2 * best;
+        if (last) loss_total = wave_sum(part) + wpp2 * best + jloss;
 
         K2B_STAMP(11);
         // ---- g. Adam (torch.optim.Adam, single-tensor path) ------------------------------------------
@@ -502,8 +560,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             const float denom = sqrtf(v1) / co.y + a.eps;
             x1 = x1 - co.x * (m1 / denom);
         }
+        }  // do_row
         K2B_STAMP(12);
     }
+    if (!do_row || !f_valid) return;
 
     // ---- 4. results -----------------------------------------------------------------------------------
     auto store_param = [&](int p, float v) {
@@ -530,14 +590,20 @@ extern "C" int k2b_debug_set_stamp_buffer(void* dev_ptr) {
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
-    // enough waves per workgroup to cover the frames with one workgroup per CU, at most MAXW
-    int waves = (a.num_frames + a.num_cus - 1) / a.num_cus;
-    waves = waves < 1 ? 1 : (waves > MAXW ? MAXW : waves);
-    const int blocks = (a.num_frames + waves - 1) / waves;
-    if (a.num_betas <= 10)
-        hipLaunchKernelGGL(k2b_fit_world_kernel<10>, dim3(blocks), dim3(waves * 64), 0, stream, a);
-    else
-        hipLaunchKernelGGL(k2b_fit_world_kernel<16>, dim3(blocks), dim3(waves * 64), 0, stream, a);
+    // frames per workgroup: enough to cover the batch with one workgroup per CU
+    int fpw = (a.num_frames + a.num_cus - 1) / a.num_cus;
+    const bool split = fpw <= MAXW / 2;            // SIMDs would idle: give every frame two cooperating waves
+    const int cap = split ? MAXW / 2 : MAXW;
+    fpw = fpw < 1 ? 1 : (fpw > cap ? cap : fpw);
+    const int blocks = (a.num_frames + fpw - 1) / fpw;
+    const dim3 block((split ? 2 * fpw : fpw) * 64);
+    if (a.num_betas <= 10) {
+        if (split) hipLaunchKernelGGL((k2b_fit_world_kernel<10, true>), dim3(blocks), block, 0, stream, a);
+        else hipLaunchKernelGGL((k2b_fit_world_kernel<10, false>), dim3(blocks), block, 0, stream, a);
+    } else {
+        if (split) hipLaunchKernelGGL((k2b_fit_world_kernel<16, true>), dim3(blocks), block, 0, stream, a);
+        else hipLaunchKernelGGL((k2b_fit_world_kernel<16, false>), dim3(blocks), block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 
