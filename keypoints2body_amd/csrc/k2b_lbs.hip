@@ -31,6 +31,7 @@ namespace k2b {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) float3v { float x, y, z; };
 
 // Fragment number of transform entry `entry` (0..11 = 4 r + e), k-step ks, frame tile `tile`:
 // [entry >> 1][ks][entry & 1][tile]: the six entry pairs are consecutive slices a constant stride
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Vertex kernel: workgroup = 8 waves = 4 frame tiles x 2 vertex tiles (128 frames x 64 vertices).
 //
-// Slices staged through LDS (ring of 3 slots), one barrier per slice, exactly 5 (pose) or 4
+// Slices staged through LDS (double-buffered), one barrier per slice, exactly 5 (pose) or 4
 // (transform) fragments loaded per wave and slice from precomputed pointers that advance by a
 // constant stride - the per-slice bookkeeping is a handful of scalar adds:
 //   pose slice  s (32-deep: k-steps 2s, 2s+1): 16 X + 24 Pd fragments, 18 MFMAs per wave
@@ -154,11 +155,11 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
 constexpr int kChunkGroups = 4;      // frame groups (128 frames each) per L2-resident chunk
 constexpr int kFragHalfs = 512;      // one fragment = 64 lanes x 8 halfs = 1 KiB
 constexpr int kSlotFrags = 40;       // fragments per ring slot
-constexpr int kMaxKA = 4;            // joints <= 64
 
 __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 ring[3][kSlotFrags][kFragHalfs];   // 120 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 wres[kMaxKA * 4][kFragHalfs];      // <= 16 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 ring[2][kSlotFrags][kFragHalfs];   // 80 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 wres[8][kFragHalfs];               // 8 KiB (KA == 2)
+    __shared__ __attribute__((aligned(16))) float parked[8][2][4][64][4];               // 64 KiB: x, y of each lane's 16 results
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar addressing
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
 
     // ---- phase 1: v_posed * kPdScale = X . Pd for the three coordinates -----------------------------
     for (int s = 0; s < KS2; ++s) {
-        const int slot = s % 3, nslot = (s + 1) % 3;
+        const int slot = s & 1, nslot = slot ^ 1;
         const bool next_pose = s + 1 < KS2;
         if (next_pose) load_pose(); else load_a();
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the slice: its latency hides under the MFMAs
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int s = KS2 + 2 * r + half, slot = s % 3, nslot = (s + 1) % 3;
+            const int s = KS2 + 2 * r + half, slot = s & 1, nslot = slot ^ 1;
             const bool more = s + 1 < nslices;
             if (more) load_a();
             __builtin_amdgcn_sched_barrier(0);
@@ -315,17 +316,37 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
             for (int i = 0; i < 16; ++i)
                 outp[i] += half == 0 ? t2[0][i] * acc[0][i] + t2[1][i] * acc[1][i] : t2[0][i] * acc[2][i] + t2[1][i];
         }
-        if (store_ok) {
-            float* orow = a.out + ((size_t)a.out_row0 + v) * 3 + r;
+        // Coordinates 0 and 1 are parked in a lane-private LDS area (4 x 16 B per lane and coordinate);
+        // with the third, every vertex leaves as ONE 12-byte store (a wave instruction covers
+        // 32 vertices x 12 B = 384 contiguous bytes per frame row).  Per-coordinate 4-byte stores
+        // reached HBM as partial lines three times over (WRITE_SIZE 2.8x the algorithmic bytes).
+        if (r < 2) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int f = frow0 + (i & 3) + 8 * (i >> 2);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&parked[wave][r][g][lane][0]) =
+                    make_float4(outp[4 * g], outp[4 * g + 1], outp[4 * g + 2], outp[4 * g + 3]);
+        } else if (store_ok) {
+            float* orow = a.out + ((size_t)a.out_row0 + v) * 3;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 px = *reinterpret_cast<const float4*>(&parked[wave][0][g][lane][0]);
+                const float4 py = *reinterpret_cast<const float4*>(&parked[wave][1][g][lane][0]);
+                const float xs4[4] = {px.x, px.y, px.z, px.w}, ys4[4] = {py.x, py.y, py.z, py.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = 4 * g + k;
+                    const int f = frow0 + (i & 3) + 8 * (i >> 2);
+                    float3v o;
+                    o.x = xs4[k];
+                    o.y = ys4[k];
+                    o.z = outp[i];
 #ifdef K2B_LBS_NOSTORE   // timing-only diagnostic build: keep the value live, drop the store
-                asm volatile("" ::"v"(outp[i]));
-                (void)orow;
+                    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z));
+                    (void)orow;
 #else
-                if (f <= flast) orow[(size_t)f * a.out_stride * 3] = outp[i];
+                    if (f <= flast) *reinterpret_cast<float3v*>(orow + (size_t)f * a.out_stride * 3) = o;
 #endif
+                }
             }
         }
     }
