@@ -190,13 +190,16 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         fit_tflops = FIT_FLOP_PER_FRAME_ITER * args.iters * F / (fit_avg * 1e-3) / 1e12
         lbs_gbs = LBS_BYTES_PER_FRAME * F / (lbs_avg * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch measured with rocprofv3 PMC passes (profiles/README.md); only known for
+        # the frame counts that were profiled
+        traffic = traffic_lbs = None
         tfile = REPO / "profiles" / "traffic_r01.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(f"fit_frames_{F}")
+                tj = json.loads(tfile.read_text())
+                traffic, traffic_lbs = tj.get(f"fit_frames_{F}"), tj.get(f"lbs_frames_{F}")
             except Exception:
-                traffic = None
+                pass
         line = {
             "metric": "SMPL frames fitted/sec (100 Adam iters, 22-joint AMASS)",
             "value": round(total_frames / elapsed, 1),
@@ -221,9 +224,9 @@ def main():
                 "traffic": traffic, "avg_launch_ms": round(fit_avg, 4),
             },
             "roofline_lbs": {
-                "kernel": "k2b_pose_setup_kernel+k2b_skin_kernel", "bound": "hbm", "achieved": round(lbs_gbs, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(lbs_gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_launch_ms": round(lbs_avg, 4),
+                "kernel": "k2b_pose_setup_kernel+k2b_lbs_mfma_kernel+k2b_gather_joints_kernel", "bound": "hbm",
+                "achieved": round(lbs_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(lbs_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_lbs, "avg_launch_ms": round(lbs_avg, 4),
                 "achieved_tflops": round(LBS_FLOP_PER_FRAME * F / (lbs_avg * 1e-3) / 1e12, 2),
             },
             "quality": {"mean_joint_error_cm": round(err_cm, 3), "mean_final_loss": round(float(out["loss"].mean()), 2)},
