@@ -88,7 +88,7 @@ void k2b_prior_destroy(k2b_prior *prior);
  * ------------------------------------------------------------------------------- */
 typedef struct k2b_fit_config {
     int32_t num_iters;          /* num_iters_first if seq_ind == 0 else num_iters_followup */
-    double step_size;           /* Adam lr (config.py:30), 1e-2.  The four Adam numbers are doubles  */
+    double step_size;           /* Adam lr (config.py:30), 1e-2 (0 = evaluate only).  Adam numbers are doubles */
     double adam_beta1;          /* 0.9     because torch keeps them as Python floats and forms     */
     double adam_beta2;          /* 0.999   1-beta, beta**t and lr/(1-beta1**t) in double before    */
     double adam_eps;            /* 1e-8    rounding to float32 (torch/optim/adam.py)               */
@@ -103,6 +103,14 @@ typedef struct k2b_fit_config {
                                    world_space.py:161-164); 1: conf is [B][K] */
     int32_t angle_prior_index[4]; /* body-pose indices of the bending prior (losses.py:16): 52,55,9,12 */
     float angle_prior_sign[4];    /* (losses.py:17): +1,-1,-1,-1 */
+    /* Parameter groups handed to the optimiser: bit 0 global_orient, 1 body_pose, 2 betas, 3 transl.
+     * 15 = world fitter (world_space.py:215-229); 9 = stage 1 of the camera-space fitter
+     * (camera_space.py:137-141: [global_orient, camera_translation]).  freeze_betas clears bit 2. */
+    int32_t optimize_mask;
+    /* w_t^2 * |transl - transl_prior_target|^2, the depth term of camera_fitting_loss_3d
+     * (losses.py:70-93: depth_loss_weight 100; its broadcast over the 4 torso joints makes the
+     * effective weight 200 in that path).  0 = off. */
+    float transl_prior_weight;
 } k2b_fit_config;
 
 void k2b_fit_config_default(k2b_fit_config *cfg);
@@ -124,6 +132,7 @@ uint32_t k2b_fit_config_size(void);
  *   conf dev [K] or [B][K] (see conf_per_frame); NULL = ones
  *   *_in dev: initial global_orient [B][3], body_pose [B][3(J-1)], betas [B][NB], transl [B][3]
  *   preserve_pose dev [B][3(J-1)] or NULL (= body_pose_in, as world_space.py:159)
+ *   transl_prior_target dev [B][3] or NULL (= transl_in): centre of the transl prior
  *   *_out dev: fitted parameters, same shapes (may alias the inputs)
  *   loss_out dev [B]: per-frame loss of the LAST iteration evaluated BEFORE its step
  *       (world_space.py:256); the reference's scalar is the sum over the batch
@@ -134,7 +143,7 @@ int k2b_fit_world(const k2b_model *model, const k2b_prior *prior, const k2b_fit_
                   int32_t num_frames, int32_t num_targets, const int32_t *model_joint_index,
                   const float *j3d, const float *conf,
                   const float *global_orient_in, const float *body_pose_in, const float *betas_in,
-                  const float *transl_in, const float *preserve_pose,
+                  const float *transl_in, const float *preserve_pose, const float *transl_prior_target,
                   float *global_orient_out, float *body_pose_out, float *betas_out, float *transl_out,
                   float *loss_out, float *grad_out, void *stream);
 

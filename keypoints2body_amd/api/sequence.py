@@ -93,6 +93,11 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
     results.append(engine.fit_frame(init_params=prev, j3d=xyz[0:1], conf_3d=conf[0], seq_ind=0,
                                     target_model_indices=model_indices))
     est = engine.estimator
+    if not hasattr(est.fitter, "fit_batch"):          # camera-space fitter: one call per frame
+        for idx in range(1, T):
+            results.append(engine.fit_frame(init_params=prev, j3d=xyz[idx: idx + 1], conf_3d=conf[idx], seq_ind=idx,
+                                            target_model_indices=model_indices))
+        return results
     out, joints, verts, loss = est.fit_batch(_repeat_params(prev, T - 1), xyz[1:], conf[1:], seq_ind=1,
                                              target_model_indices=model_indices, per_frame_conf=True)
     for i in range(T - 1):

@@ -4,8 +4,8 @@ Counterpart of the reference's ``OptimizationEstimator``
 (reference ``keypoints2body/core/estimators/optimization.py:14-85``): it picks the fitter
 from ``model_type`` / ``coordinate_mode`` and injects ``joint_loss_weight``,
 ``pose_preserve_weight`` and ``freeze_betas`` from the frame config on every call.
-Only the world-space SMPL-family fitter exists on the HIP engine so far; the other
-branches of the reference's dispatch raise ``NotImplementedError`` naming what is missing.
+World- and camera-space SMPL-family fitters exist on the HIP engine; the MANO / FLAME branches of
+the reference's dispatch raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -15,6 +15,7 @@ import torch
 
 from ...models.smpl_data import BodyModelFitResult, BodyModelParams
 from ..config import FrameOptimizeConfig
+from ..fitters.camera_space import CameraSpaceFitter
 from ..fitters.world_space import WorldSpaceFitter
 
 
@@ -27,9 +28,11 @@ class OptimizationEstimator:
                 f"body_model='{model_type}': the MANO/FLAME fitters (reference core/fitters/misc_models.py) "
                 "are outside the HIP engine's scope")
         if frame_config.coordinate_mode == "camera":
-            raise NotImplementedError(
-                "coordinate_mode='camera': the two-stage camera-space fitter (reference "
-                "core/fitters/camera_space.py) is not built on the HIP engine yet; use coordinate_mode='world'")
+            self._fitter = CameraSpaceFitter(
+                smpl_model=model, step_size=frame_config.step_size, num_iters=frame_config.num_iters,
+                use_lbfgs=frame_config.use_lbfgs, joints_category=frame_config.joints_category, device=device,
+                pose_prior_num_gaussians=frame_config.pose_prior_num_gaussians, pose_prior=pose_prior)
+            return
         self._fitter = WorldSpaceFitter(
             smpl_model=model, step_size=frame_config.step_size, num_iters_first=frame_config.num_iters_first,
             num_iters_followup=frame_config.num_iters_followup, use_lbfgs=frame_config.use_lbfgs,
@@ -37,7 +40,7 @@ class OptimizationEstimator:
             pose_prior_num_gaussians=frame_config.pose_prior_num_gaussians, pose_prior=pose_prior)
 
     @property
-    def fitter(self) -> WorldSpaceFitter:
+    def fitter(self):
         return self._fitter
 
     def _weights(self):

@@ -1,0 +1,136 @@
+"""Camera-space two-stage fitter on the HIP engine.
+
+Drop-in for the Adam branch of the reference's ``CameraSpaceFitter``
+(reference ``keypoints2body/core/fitters/camera_space.py:44-339``).  Both stages run in the same
+fused kernel as the world fitter (``k2b_fit_world``): the camera translation takes the place of
+``transl`` (it is added to the joints inside the loss, ``core/losses.py:46-47``), and the stages
+differ only in the fit configuration:
+
+* stage 1 (``camera_space.py:183-213``): optimise ``[global_orient, camera_translation]``
+  (``optimize_mask = 9``) against the four torso joints with a plain squared error
+  (GMoF with sigma -> inf) plus the depth prior ``100^2 |t - t0|^2``, which the reference's
+  broadcast adds once per torso joint (``losses.py:91-93``: effective weight ``200^2``);
+  all pose / shape priors off (the mixture is skipped in-kernel);
+* stage 2 (``camera_space.py:268-298``): ``body_fitting_loss_3d`` over all targets; betas are
+  optimised iff ``seq_ind == 0 or not freeze_betas`` (``:219-224``); a fresh optimiser state;
+* result (``:300-339``): model-space joints / vertices (no translation applied), ``params.transl``
+  = camera translation, ``loss`` = the loss re-evaluated at the fitted parameters with joint
+  weight 600 and no preserve term (an evaluate-only launch: one iteration with step size 0).
+
+Like the reference (whose broadcasts only hold for one frame per call) ``fit_frame`` treats every
+frame independently; unlike it, any number of frames may be passed at once.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ... import native
+from ...models.body_model import BodyModel, as_body_model
+from ...models.smpl_data import BodyModelFitResult, SMPLData
+from ...prior import MaxMixturePrior
+from ..constants import JOINT_MAP, TORSO_JOINTS, category_indices
+
+_TORSO_IDX = [JOINT_MAP[name] for name in TORSO_JOINTS]     # same indices in the AMASS numbering
+_SQUARED_ERROR_SIGMA = 1.0e8                                # gmof(e, sigma) -> e^2 in fp32
+
+
+def guess_init_3d(model_joints, j3d, joints_category="SMPL24"):
+    """Initial camera translation: mean offset of the four torso joints
+    (reference ``camera_space.py:16-41``)."""
+    if joints_category not in ("SMPL24", "AMASS"):
+        raise ValueError(f"Unknown joints category: {joints_category}")
+    return (j3d[:, _TORSO_IDX] - model_joints[:, _TORSO_IDX]).sum(dim=1) / 4.0
+
+
+class CameraSpaceFitter:
+    """Per-frame optimizer operating in camera coordinates, executed on one MI355X."""
+
+    def __init__(self, smpl_model, step_size=1e-2, num_iters=100, use_lbfgs=True, joints_category="SMPL24",
+                 device=None, pose_prior_num_gaussians=8, pose_prior: Optional[MaxMixturePrior] = None):
+        self.smpl: BodyModel = as_body_model(smpl_model, device=device)
+        self.device = self.smpl.device
+        self.step_size = step_size
+        self.num_iters = num_iters
+        self.use_lbfgs = use_lbfgs
+        self.joints_category = joints_category
+        self.smpl_index, self.corr_index = category_indices(joints_category)
+        self.pose_prior = pose_prior if pose_prior is not None else MaxMixturePrior(
+            prior_folder="./data/models/", num_gaussians=pose_prior_num_gaussians, device=self.device)
+
+    def _dev(self, x, cols) -> torch.Tensor:
+        t = torch.as_tensor(x, dtype=torch.float32).detach().to(self.device)
+        if t.dim() != 2 or t.shape[1] != cols:
+            raise ValueError(f"expected a (B,{cols}) tensor, got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def fit_frame(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
+                  seq_ind: int = 0, target_model_indices: Optional[torch.Tensor] = None,
+                  joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = True,
+                  init_cam_t: Optional[torch.Tensor] = None) -> BodyModelFitResult:
+        if self.use_lbfgs:
+            raise NotImplementedError(
+                "use_lbfgs=True: the HIP engine implements the Adam branch of CameraSpaceFitter only; "
+                "set FrameOptimizeConfig(use_lbfgs=False)")
+        J = self.smpl.num_joints
+        go = self._dev(init_params.global_orient, 3)
+        bp = self._dev(init_params.body_pose, 3 * (J - 1))
+        be = self._dev(init_params.betas, self.smpl.num_betas)
+        j3d = torch.as_tensor(j3d, dtype=torch.float32).to(self.device)
+        B = j3d.shape[0]
+        if not (go.shape[0] == bp.shape[0] == be.shape[0] == B):
+            raise ValueError("init_params and j3d disagree on the number of frames")
+
+        if target_model_indices is None:
+            if self.smpl_index is None:
+                raise ValueError("joints_category='GENERIC' needs target_model_indices")
+            model_idx, targets = list(self.smpl_index), j3d[:, list(self.corr_index)].contiguous()
+            stage1_idx, stage1_tgt, depth_w = _TORSO_IDX, j3d[:, _TORSO_IDX].contiguous(), 200.0
+        else:
+            model_idx = [int(i) for i in torch.as_tensor(target_model_indices).reshape(-1).tolist()]
+            targets = j3d.contiguous()
+            stage1_idx, stage1_tgt, depth_w = model_idx, targets, 100.0          # camera_space.py:199-210
+        conf = None if conf_3d is None else torch.as_tensor(conf_3d, dtype=torch.float32).to(self.device).contiguous()
+
+        # initial camera translation (camera_space.py:110-134)
+        if init_cam_t is None:
+            joints0 = self.smpl(global_orient=go, body_pose=bp, betas=be, return_verts=False).joints
+            if target_model_indices is None:
+                cam_t0 = guess_init_3d(joints0, j3d, self.joints_category)
+            else:
+                cam_t0 = j3d[:, 0, :] - joints0[:, model_idx[0], :]
+        else:
+            cam_t0 = torch.as_tensor(init_cam_t, dtype=torch.float32).to(self.device)
+        cam_t0 = cam_t0.detach().contiguous()
+
+        fit = lambda cfg, idx, tgt, cf, p: native.fit_world(
+            self.smpl.native, self.pose_prior.native, cfg, idx, tgt, cf, p["global_orient"], p["body_pose"],
+            p["betas"], p["transl"], transl_prior_target=cam_t0)
+
+        # stage 1: [global_orient, camera_translation] on the torso joints
+        cfg = native.default_fit_config()
+        cfg.num_iters, cfg.step_size = int(self.num_iters), float(self.step_size)
+        cfg.sigma, cfg.joint_loss_weight = _SQUARED_ERROR_SIGMA, 1.0
+        cfg.pose_prior_weight = cfg.angle_prior_weight = cfg.shape_prior_weight = cfg.pose_preserve_weight = 0.0
+        cfg.optimize_mask, cfg.transl_prior_weight = 9, depth_w
+        s1 = fit(cfg, stage1_idx, stage1_tgt, None, dict(global_orient=go, body_pose=bp, betas=be, transl=cam_t0))
+
+        # stage 2: body fit with a fresh optimiser state
+        cfg = native.default_fit_config()
+        cfg.num_iters, cfg.step_size = int(self.num_iters), float(self.step_size)
+        cfg.joint_loss_weight = float(joint_loss_weight)
+        cfg.pose_preserve_weight = float(pose_preserve_weight) if seq_ind > 0 else 0.0
+        cfg.optimize_mask = 15 if (seq_ind == 0 or not freeze_betas) else 11
+        s2 = fit(cfg, model_idx, targets, conf, s1)
+
+        # loss at the fitted parameters: weight 600, no preserve term (camera_space.py:316-326)
+        cfg = native.default_fit_config()
+        cfg.num_iters, cfg.step_size, cfg.joint_loss_weight = 1, 0.0, 600.0
+        final = fit(cfg, model_idx, targets, conf, s2)
+
+        joints, verts = self.smpl.native.lbs(s2["global_orient"], s2["body_pose"], s2["betas"], None)
+        return BodyModelFitResult(
+            params=SMPLData(betas=s2["betas"], global_orient=s2["global_orient"], body_pose=s2["body_pose"],
+                            transl=s2["transl"]),
+            vertices=verts, joints=joints, loss=final["loss"].sum())

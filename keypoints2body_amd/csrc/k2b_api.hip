@@ -113,6 +113,8 @@ void k2b_fit_config_default(k2b_fit_config* c) {
     const int idx[4] = {52, 55, 9, 12};
     const float sg[4] = {1.f, -1.f, -1.f, -1.f};
     for (int i = 0; i < 4; ++i) { c->angle_prior_index[i] = idx[i]; c->angle_prior_sign[i] = sg[i]; }
+    c->optimize_mask = 15;
+    c->transl_prior_weight = 0.0f;
 }
 
 int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t E, const float* v_template,
@@ -396,7 +398,8 @@ void k2b_prior_destroy(k2b_prior* p) {
 
 int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
                   const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
-                  const float* bp_in, const float* be_in, const float* tr_in, const float* preserve, float* go_out,
+                  const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
+                  const float* tr_prior, float* go_out,
                   float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream) {
     k2b_model* model = const_cast<k2b_model*>(model_c);
     if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
@@ -406,7 +409,7 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     if (K < 1 || K > model->J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_targets=%d out of range", K);
     if (!model_joint_index) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index is NULL");
     if (cfg->num_iters < 1 || cfg->num_iters > (1 << 20)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_iters=%d", cfg->num_iters);
-    if (!(cfg->step_size > 0.0) || !(cfg->adam_beta1 >= 0.0 && cfg->adam_beta1 < 1.0) || !(cfg->adam_beta2 >= 0.0 && cfg->adam_beta2 < 1.0))
+    if (!(cfg->step_size >= 0.0) || !(cfg->adam_beta1 >= 0.0 && cfg->adam_beta1 < 1.0) || !(cfg->adam_beta2 >= 0.0 && cfg->adam_beta2 < 1.0))
         return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: bad Adam hyper-parameters");
     if (B == 0) return K2B_OK;
     if (!j3d || !go_in || !bp_in || !be_in || !tr_in || !go_out || !bp_out || !be_out || !tr_out)
@@ -458,6 +461,7 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     memcpy(a.lane_target, lane_target, sizeof lane_target);
     a.j3d = j3d; a.conf = conf; a.conf_per_frame = cfg->conf_per_frame ? 1 : 0;
     a.go_in = go_in; a.bp_in = bp_in; a.be_in = be_in; a.tr_in = tr_in; a.preserve = preserve;
+    a.tr_prior = tr_prior ? tr_prior : tr_in;
     a.go_out = go_out; a.bp_out = bp_out; a.be_out = be_out; a.tr_out = tr_out;
     a.loss_out = loss_out; a.grad_out = grad_out;
     a.adam_coef = coef; a.num_iters = cfg->num_iters;
@@ -468,6 +472,8 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     a.sigma = cfg->sigma; a.joint_w = cfg->joint_loss_weight; a.pose_prior_w = cfg->pose_prior_weight;
     a.angle_w = cfg->angle_prior_weight; a.shape_w = cfg->shape_prior_weight; a.preserve_w = cfg->pose_preserve_weight;
     a.freeze_betas = cfg->freeze_betas ? 1 : 0;
+    a.opt_mask = (cfg->optimize_mask & 15) & (cfg->freeze_betas ? ~4 : ~0);
+    a.transl_prior_w = cfg->transl_prior_weight;
     a.num_cus = device_cus();
     HIP_TRY(k2b::launch_fit_world(a, (hipStream_t)stream));
     return K2B_OK;

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const bool actB = lane < nparamB;
     const bool bodyA = lane >= 3, bodyB = lane < 8;
     const bool betaB = lane >= 8 && lane < 8 + NB;
-    const bool optB = actB && !(betaB && a.freeze_betas);
+    const bool translB = actB && !bodyB && !betaB;
+    // optimiser membership of this lane's parameters (k2b_fit_config.optimize_mask)
+    const bool optA = (a.opt_mask >> (lane < 3 ? 0 : 1)) & 1;
+    const bool optB = actB && ((a.opt_mask >> (bodyB ? 1 : (betaB ? 2 : 3))) & 1);
 
     float muA[MG], cA[MG];
 #pragma unroll
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const float* prsrc = a.preserve ? a.preserve : a.bp_in;
     const float pr0 = bodyA ? prsrc[(size_t)f * D + (lane - 3)] : 0.f;
     const float pr1 = bodyB ? prsrc[(size_t)f * D + 61 + lane] : 0.f;
+    const float tp1 = translB ? a.tr_prior[(size_t)f * 3 + (lane - 8 - NB)] : 0.f;   // centre of the transl prior
     float m0 = 0.f, v0 = 0.f, m1 = 0.f, v1 = 0.f;
 
     const float s2 = a.sigma * a.sigma;
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const float wa2 = a.angle_w * a.angle_w;
     const float ws2 = a.shape_w * a.shape_w;
     const float wpr2 = a.preserve_w * a.preserve_w;
+    const float wt2 = a.transl_prior_w * a.transl_prior_w;
     const float om_b1 = a.one_minus_beta1;       // lerp weight float(1 - beta1), formed in double on host
     const float om_b2 = a.one_minus_beta2;       // float(1 - beta2) computed in double on host
 
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 
         K2B_STAMP(1);
         float yA = 0.f, yBs = 0.f, best = 0.f;
-        if (do_row) {
+        if (do_row && wpp2 != 0.f) {   // a zero pose-prior weight (camera stage 1) skips the mixture entirely
         // ---- c. GMM prior: y_m = P_m theta - P_m mu_m for every component ----------------------
         // rows 0..60 (set A).  Hand-pipelined: block jb+1's nine ds_read_b128 are in flight
         // while block jb's 32 FMAs issue.
@@ -543,12 +548,16 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             g1 += 2.f * ws2 * x1;
             if (last) part += ws2 * x1 * x1;
         }
+        if (translB) {
+            g1 += 2.f * wt2 * (x1 - tp1);
+            if (last) part += wt2 * (x1 - tp1) * (x1 - tp1);
+        }
         if (last) loss_total = wave_sum(part) + wpp2 * best + jloss;
 
         K2B_STAMP(11);
         // ---- g. Adam (torch.optim.Adam, single-tensor path) ------------------------------------------
         const float2 co = a.adam_coef[it];     // {lr / (1 - b1^t), sqrt(1 - b2^t)}
-        {
+        if (optA) {
             m0 = m0 + om_b1 * (g0 - m0);
             v0 = v0 * a.beta2 + om_b2 * g0 * g0;
             const float denom = sqrtf(v0) / co.y + a.eps;
@@ -577,8 +586,8 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     if (lane == 0 && a.loss_out) a.loss_out[f] = loss_total;
     if (a.grad_out) {
         const int P = 3 + D + NB + 3;
-        a.grad_out[(size_t)f * P + lane] = g0;
-        if (actB) a.grad_out[(size_t)f * P + 64 + lane] = (betaB && a.freeze_betas) ? 0.f : g1;
+        a.grad_out[(size_t)f * P + lane] = optA ? g0 : 0.f;
+        if (actB) a.grad_out[(size_t)f * P + 64 + lane] = optB ? g1 : 0.f;
     }
 }
 

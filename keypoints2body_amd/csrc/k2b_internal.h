@@ -39,13 +39,15 @@ struct FitArgs {
     const float* j3d;
     const float* conf;
     int conf_per_frame;
-    const float *go_in, *bp_in, *be_in, *tr_in, *preserve;
+    const float *go_in, *bp_in, *be_in, *tr_in, *preserve, *tr_prior;
     float *go_out, *bp_out, *be_out, *tr_out, *loss_out, *grad_out;
     const float2* adam_coef;    // [num_iters] {lr / (1 - b1^t), sqrt(1 - b2^t)}
     int num_iters;
     float one_minus_beta1, beta2, one_minus_beta2, eps;
     float sigma, joint_w, pose_prior_w, angle_w, shape_w, preserve_w;
     int freeze_betas;
+    int opt_mask;               // bit 0 global_orient, 1 body_pose, 2 betas, 3 transl
+    float transl_prior_w;
     int angle_index[4];
     float angle_sign[4];
     int num_cus;

@@ -49,6 +49,8 @@ class FitConfigC(C.Structure):
         ("conf_per_frame", C.c_int32),
         ("angle_prior_index", C.c_int32 * 4),
         ("angle_prior_sign", C.c_float * 4),
+        ("optimize_mask", C.c_int32),
+        ("transl_prior_weight", C.c_float),
     ]
 
 
@@ -90,7 +92,7 @@ def load_library():
     if lib.k2b_fit_config_size() != C.sizeof(FitConfigC):
         raise RuntimeError("libk2b.so was built with a different k2b_fit_config layout than native.FitConfigC")
     lib.k2b_fit_world.restype = C.c_int
-    lib.k2b_fit_world.argtypes = [vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 13 + [vp]
+    lib.k2b_fit_world.argtypes = [vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 14 + [vp]
     lib.k2b_lbs.restype = C.c_int
     lib.k2b_lbs.argtypes = [vp, C.c_int32] + [fp] * 6 + [vp]
     _lib = lib
@@ -252,7 +254,7 @@ def default_fit_config() -> FitConfigC:
 def fit_world(model: NativeModel, prior: NativePrior, cfg: FitConfigC, model_joint_index: Sequence[int],
               j3d: torch.Tensor, conf: Optional[torch.Tensor], global_orient: torch.Tensor, body_pose: torch.Tensor,
               betas: torch.Tensor, transl: torch.Tensor, preserve_pose: Optional[torch.Tensor] = None,
-              want_grad: bool = False):
+              want_grad: bool = False, transl_prior_target: Optional[torch.Tensor] = None):
     """Launch the fused fit on the current stream; returns a dict of device tensors."""
     dev = model.device
     B, K = j3d.shape[0], j3d.shape[1]
@@ -283,6 +285,7 @@ def fit_world(model: NativeModel, prior: NativePrior, cfg: FitConfigC, model_joi
             _dev(global_orient, "global_orient", dev, (B, 3)), _dev(body_pose, "body_pose", dev, (B, D)),
             _dev(betas, "betas", dev, (B, model.num_betas)), _dev(transl, "transl", dev, (B, 3)),
             _dev(preserve_pose, "preserve_pose", dev, (B, D)),
+            _dev(transl_prior_target, "transl_prior_target", dev, (B, 3)),
             C.c_void_p(out["global_orient"].data_ptr()), C.c_void_p(out["body_pose"].data_ptr()),
             C.c_void_p(out["betas"].data_ptr()), C.c_void_p(out["transl"].data_ptr()),
             C.c_void_p(out["loss"].data_ptr()),

@@ -182,3 +182,79 @@ def guess_init_transl(model, pose_aa, betas, j3d, root_model: int = 0, root_targ
     with torch.no_grad():
         out = model(global_orient=pose_aa[:, :3], body_pose=pose_aa[:, 3:], betas=betas)
     return (j3d[:, root_target, :] - out.joints[:, root_model, :]).detach()
+
+
+# ---------------------------------------------------------------------------------------------
+# Camera-space two-stage fitter (reference core/fitters/camera_space.py:81-339,
+# camera_fitting_loss_3d core/losses.py:70-93, guess_init_3d camera_space.py:16-41).
+# Pinned by tests/golden/camera_fit_*.npz (oracle/gen_golden.py runs the reference class).
+# The reference's broadcasts (losses.py:46-47, 91-93) are only valid for one frame per call, so
+# this restatement fits ONE frame per call too; batches loop.
+# ---------------------------------------------------------------------------------------------
+TORSO = (2, 1, 17, 16)     # RHip, LHip, RShoulder, LShoulder in both SMPL24 and AMASS numbering
+
+
+def guess_init_cam_t(model_joints, j3d):
+    idx = list(TORSO)
+    return (j3d[:, idx] - model_joints[:, idx]).sum(dim=1) / 4.0
+
+
+def camera_stage1_loss(model_joints, cam_t, cam_t_est, j3d, depth_loss_weight=100.0):
+    idx = list(TORSO)
+    err = (j3d[:, idx] - (model_joints + cam_t)[:, idx]) ** 2            # (1,4,3)
+    depth = (depth_loss_weight ** 2) * (cam_t - cam_t_est) ** 2           # (1,3): broadcast over the 4 joints
+    return (err + depth).sum()
+
+
+def fit_camera_adam_one(model, prior: GMMPrior, global_orient, body_pose, betas, j3d, conf=None, *, num_iters: int,
+                        lr: float = 1e-2, seq_ind: int = 0, freeze_betas: bool = False,
+                        weights: Optional[FitWeights] = None, model_idx: Optional[Sequence[int]] = None,
+                        init_cam_t: Optional[torch.Tensor] = None) -> FitOutput:
+    """Both Adam stages for ONE frame (all tensors have a leading dimension of 1)."""
+    w = weights or FitWeights()
+    go = global_orient.clone().detach()
+    bp = body_pose.clone().detach()
+    be = betas.clone().detach()
+    K = j3d.shape[1]
+    idx = list(range(K)) if model_idx is None else list(model_idx)
+    with torch.no_grad():
+        j0 = model(global_orient=go, body_pose=bp, betas=be).joints
+    # camera_space.py:123-134: the caller may supply the initial translation (it is then also the
+    # centre of the depth prior)
+    t0 = guess_init_cam_t(j0, j3d).detach() if init_cam_t is None else init_cam_t.detach().clone()
+    cam_t = t0.clone()
+    preserve = bp.clone().detach()
+    conf = torch.ones(K) if conf is None else conf
+
+    go.requires_grad_(True)
+    cam_t.requires_grad_(True)
+    opt = torch.optim.Adam([go, cam_t], lr=lr, betas=(0.9, 0.999))
+    for _ in range(num_iters):                                   # stage 1: camera_space.py:183-213
+        joints = model(global_orient=go, body_pose=bp, betas=be).joints
+        loss = camera_stage1_loss(joints[:, idx], cam_t, t0, j3d)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    stage1 = (go.detach().clone(), cam_t.detach().clone())
+
+    bp.requires_grad_(True)
+    opt_betas = seq_ind == 0 or not freeze_betas                 # camera_space.py:219-224
+    be.requires_grad_(opt_betas)
+    params = [bp] + ([be] if opt_betas else []) + [go, cam_t]
+    opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999))
+    for _ in range(num_iters):                                   # stage 2: camera_space.py:268-298
+        joints = model(global_orient=go, body_pose=bp, betas=be).joints
+        loss = frame_losses(bp, preserve, be, joints[:, idx] + cam_t, j3d, prior, conf, w,
+                            preserve_on=seq_ind > 0).sum()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    with torch.no_grad():                                        # final: camera_space.py:300-326
+        out = model(global_orient=go, body_pose=bp, betas=be, return_full_pose=False)
+        wf = FitWeights(**{**w.__dict__, "joint_loss_weight": 600.0})
+        final = frame_losses(bp, preserve, be, out.joints[:, idx] + cam_t, j3d, prior, conf, wf, preserve_on=False)
+    res = FitOutput(go.detach(), bp.detach(), be.detach(), cam_t.detach(), out.joints.detach(),
+                    out.vertices.detach(), final.detach())
+    res.stage1 = stage1
+    res.init_cam_t = t0
+    return res

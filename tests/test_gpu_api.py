@@ -118,3 +118,42 @@ def test_sequence_warm_start_chain_matches_oracle(assets):
         prev = dict(go=o.global_orient, bp=o.body_pose, be=o.betas, tr=o.transl)
     last = k2b.optimize_shape_sequence(seq, model=model, config=cfg, pose_prior=prior, mean_params=_mean_params(d))
     assert torch.equal(last.body_pose, res[-1].params.body_pose)
+
+
+@pytest.mark.parametrize("case", ["full", "followup_frozen", "default_start"])
+def test_camera_space_fitter_matches_reference_golden(assets, case):
+    """Two-stage camera-space fit on the HIP engine vs the reference's CameraSpaceFitter."""
+    from keypoints2body_amd.core.fitters.camera_space import CameraSpaceFitter
+    model, prior = assets
+    d = dict(np.load(H.GOLDEN / f"camera_fit_{case}.npz"))
+    fitter = CameraSpaceFitter(model, step_size=1e-2, num_iters=int(d["num_iters"]), use_lbfgs=False,
+                               joints_category="AMASS", pose_prior=prior)
+    conf = torch.tensor(d["conf"]) if int(d["has_conf"]) else None
+    init = k2b.SMPLData(betas=torch.tensor(d["init_betas"]), global_orient=torch.tensor(d["init_global_orient"]),
+                        body_pose=torch.tensor(d["init_body_pose"]))
+    res = fitter.fit_frame(init, torch.tensor(d["j3d"]), conf_3d=conf, seq_ind=int(d["seq_ind"]),
+                           freeze_betas=bool(int(d["freeze_betas"])),
+                           init_cam_t=torch.tensor(d["init_cam_t"]) if int(d["has_init_cam_t"]) else None)
+    # With the reference's DEFAULT start (camera_t = mean torso offset) d loss / d camera_t at the first
+    # stage-1 step is rounding noise around zero and Adam's first step is scale-free, so that result is
+    # only defined to ~1e-3 on any fp32 implementation (two CPUs running the reference differ by as
+    # much).  The pinned cases pass `init_cam_t` (a start a few cm off) and keep the 1e-4 gate.
+    tol = TOL if int(d["has_init_cam_t"]) else 1e-2
+    for key in ("global_orient", "body_pose", "betas", "transl"):
+        err = np.abs(getattr(res.params, key).cpu().numpy() - d["out_" + key]).max()
+        assert err < tol, (case, key, err)
+    assert np.abs(res.joints.cpu().numpy() - d["out_joints"]).max() < tol
+    vs = res.vertices[:, torch.as_tensor(d["sampled_vertex_ids"]).cuda()].cpu().numpy()
+    assert np.abs(vs - d["out_verts_sampled"]).max() < tol
+    np.testing.assert_allclose(float(res.loss), float(d["out_loss"].sum()), rtol=2e-5 if tol == TOL else 2e-2)
+    if int(d["freeze_betas"]) and int(d["seq_ind"]) > 0:
+        assert torch.equal(res.params.betas.cpu(), torch.tensor(d["init_betas"]))
+    # through the public API: coordinate_mode='camera'
+    cfg = FrameOptimizeConfig(use_lbfgs=False, coordinate_mode="camera", num_iters=int(d["num_iters"]))
+    joints = np.concatenate([d["j3d"][0], (d["conf"] if int(d["has_conf"]) else np.ones(22, np.float32))[:, None]], axis=1)
+    mp = torch.tensor(np.concatenate([d["init_global_orient"][:1], d["init_body_pose"][:1]], axis=1))
+    if int(d["seq_ind"]) == 0 and not int(d["has_init_cam_t"]):
+        r1 = k2b.optimize_params_frame(joints, joint_layout="AMASS", model=model, config=cfg, pose_prior=prior,
+                                       mean_params=(mp, torch.tensor(d["init_betas"][:1])))
+        assert np.abs(r1.params.body_pose.cpu().numpy() - d["out_body_pose"][:1]).max() < tol
+        assert np.abs(r1.params.transl.cpu().numpy() - d["out_transl"][:1]).max() < tol

@@ -53,3 +53,24 @@ def test_oracle_reproduces_reference_fit(case):
         np.testing.assert_allclose(mine.sum(axis=1)[None], ref, rtol=1e-5)
     if int(d["freeze_betas"]):
         assert np.array_equal(out.betas.numpy(), d["init_betas"])
+
+
+CAMERA_CASES = ("full", "followup_frozen")
+
+
+@pytest.mark.parametrize("case", CAMERA_CASES)
+def test_oracle_reproduces_reference_camera_fit(case):
+    """The camera-space restatement (two Adam stages) vs the reference's CameraSpaceFitter."""
+    from oracle.fit_torch import fit_camera_adam_one
+    d = dict(np.load(H.GOLDEN / f"camera_fit_{case}.npz"))
+    conf = torch.tensor(d["conf"]) if int(d["has_conf"]) else None
+    for i in range(d["j3d"].shape[0]):
+        t = lambda k: torch.tensor(d[k][i:i + 1])
+        o = fit_camera_adam_one(H.oracle_model(), H.oracle_prior(), t("init_global_orient"), t("init_body_pose"),
+                                t("init_betas"), t("j3d"), conf, num_iters=int(d["num_iters"]),
+                                seq_ind=int(d["seq_ind"]), freeze_betas=bool(int(d["freeze_betas"])),
+                                init_cam_t=t("init_cam_t") if int(d["has_init_cam_t"]) else None)
+        for key, val in (("global_orient", o.global_orient), ("body_pose", o.body_pose), ("betas", o.betas),
+                         ("transl", o.transl), ("joints", o.joints)):
+            assert np.abs(val.numpy() - d["out_" + key][i:i + 1]).max() < 5e-6, (case, i, key)
+        np.testing.assert_allclose(float(o.loss), float(d["out_loss"][i]), rtol=1e-5)
