@@ -59,7 +59,7 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
     if frame_cfg.joints_category != "GENERIC":
         betas_opt = optimize_shape_pass(model=model, seq_config=seq_cfg, init_mean_shape=mean_shape,
                                         init_mean_pose=mean_pose, data_tensor=xyz, confidence_input=conf[0],
-                                        device=device)
+                                        device=device, pose_prior=pose_prior)
     engine = OptimizeEngine(model=model, frame_config=frame_cfg, device=device, model_type=body_model,
                             pose_prior=pose_prior)
     if xyz.shape[0] == 0:

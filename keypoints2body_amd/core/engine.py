@@ -95,13 +95,73 @@ def upgrade_smpl_family_init_params(base: SMPLData, model_type: str, model, devi
 
 
 def optimize_shape_pass(model, seq_config: SequenceOptimizeConfig, init_mean_shape, init_mean_pose, data_tensor,
-                        confidence_input, device):
+                        confidence_input, device, pose_prior=None):
     """Multi-frame shared-betas pre-pass (reference ``core/engine.py:217-262`` ->
-    ``core/shape.py:10-115``).  Not built on the HIP engine yet; note that the
-    reference's own Adam branch of this pass raises (``shape.py:10,110-113``), so Adam runs of the
-    reference need ``use_shape_optimization=False`` as well."""
+    ``optimize_shape_multi_frame``, ``core/shape.py:10-115``).
+
+    Loss over the first ``num_shape_frames`` frames at the mean pose: per frame
+    ``sum_k conf_k^2 |(p_k - p_root)(beta) - (y_k - y_root)|^2 + w_s^2 |beta|^2`` (the per-frame
+    translation is the root alignment, so it depends on beta through the rest root joint only).
+    The reference runs ``torch.optim.LBFGS([betas], max_iter=num_shape_iters, lr=0.1,
+    strong_wolfe)``; so does this function, with loss and gradient of every closure evaluation
+    computed by ONE evaluate-only launch of the fused kernel over all frames (squared error via
+    GMoF sigma -> inf, pose priors off) and the chain rule through the root alignment applied on
+    the 10-vector.  The reference's Adam branch of this pass raises (``shape.py:10,110-113``:
+    ``closure()`` under ``no_grad`` and no optimiser step), so ``use_lbfgs=False`` is rejected here
+    with an explicit error instead.
+    """
     if not seq_config.use_shape_optimization:
         return init_mean_shape
-    raise NotImplementedError(
-        "use_shape_optimization=True: the shared-shape pre-pass is not built on the HIP engine yet; "
-        "set SequenceOptimizeConfig(use_shape_optimization=False)")
+    if not seq_config.frame.use_lbfgs:
+        raise RuntimeError(
+            "use_shape_optimization=True with use_lbfgs=False: the reference's Adam branch of the shape "
+            "pre-pass raises (core/shape.py:10,110-113); set use_shape_optimization=False or use_lbfgs=True")
+    from .. import native
+    from ..prior import MaxMixturePrior
+    from .constants import category_indices, root_indices
+
+    m = as_body_model(model)
+    dev = m.device
+    cat = seq_config.frame.joints_category
+    smpl_index, corr_index = category_indices(cat)
+    if smpl_index is None:
+        raise ValueError(f"No such joints category: {cat}")
+    root_model, root_target = root_indices(cat)
+    t_size = data_tensor.shape[0]
+    n = t_size if (seq_config.num_shape_frames < 0 or seq_config.num_shape_frames >= t_size) else seq_config.num_shape_frames
+    y = torch.as_tensor(data_tensor, dtype=torch.float32).to(dev)[:n]
+    targets = y[:, list(corr_index)].contiguous()
+    conf = torch.as_tensor(confidence_input, dtype=torch.float32).to(dev)
+    conf = (conf if conf.dim() == 1 else conf[0])[list(corr_index)].contiguous()
+    pose = torch.as_tensor(init_mean_pose, dtype=torch.float32).to(dev).expand(n, -1).contiguous()
+    go, bp = pose[:, :3].contiguous(), pose[:, 3:].contiguous()
+    prior = pose_prior if pose_prior is not None else MaxMixturePrior(
+        prior_folder="./data/models/", num_gaussians=seq_config.frame.pose_prior_num_gaussians, device=dev)
+    jt, jd = m.native.joint_basis()                  # rest root joint = J_template[0] + J_dirs[0] . beta
+    jt0 = torch.as_tensor(jt[root_model], device=dev)
+    jd0 = torch.as_tensor(jd[root_model], device=dev)          # (3, NB)
+
+    cfg = native.default_fit_config()
+    cfg.num_iters, cfg.step_size = 1, 0.0
+    cfg.sigma, cfg.joint_loss_weight = 1.0e8, 1.0             # plain squared error
+    cfg.pose_prior_weight = cfg.angle_prior_weight = cfg.pose_preserve_weight = 0.0
+    cfg.shape_prior_weight = float(seq_config.frame.shape_prior_weight)
+
+    betas = torch.as_tensor(init_mean_shape, dtype=torch.float32).to(dev).clone().reshape(1, -1).requires_grad_(True)
+
+    def closure():
+        with torch.no_grad():
+            b = betas.detach()
+            transl = (y[:, root_target] - (jt0 + jd0 @ b[0])).contiguous()         # root alignment, (n,3)
+            r = native.fit_world(m.native, prior.native, cfg, list(smpl_index), targets, conf, go, bp,
+                                 b.expand(n, -1).contiguous(), transl, want_grad=True)
+            g = r["grad"]
+            nb = b.shape[1]
+            g_beta = g[:, 3 + bp.shape[1]:3 + bp.shape[1] + nb].sum(dim=0)
+            g_transl = g[:, 3 + bp.shape[1] + nb:].sum(dim=0)
+            betas.grad = (g_beta - jd0.t() @ g_transl).reshape(1, -1)              # d transl / d beta = -J_dirs[root]
+            return r["loss"].sum()
+
+    torch.optim.LBFGS([betas], max_iter=int(seq_config.num_shape_iters), lr=1e-1,
+                      line_search_fn="strong_wolfe").step(closure)
+    return betas.detach()

@@ -8,10 +8,14 @@ class validates its inputs, uploads them and makes ONE call into ``libk2b.so``
 (``k2b_fit_world``: all iterations fused in one kernel, one frame per wavefront) plus
 one ``k2b_lbs`` call for the final vertices/joints (``world_space.py:258-278``).
 
+``use_lbfgs=True`` (the reference's default, ``world_space.py:231-247``) keeps
+``torch.optim.LBFGS`` (strong Wolfe) as the outer algorithm, exactly as the reference does, but its
+closure no longer builds an autograd graph: loss and gradient of every evaluation come from an
+evaluate-only launch of the same kernel (``step_size = 0``, ``grad_out``).  L-BFGS couples all
+parameters it is given, so frames are fitted one at a time in that mode, like the reference.
+
 Differences, all deliberate and documented in DESIGN.md:
 
-* ``use_lbfgs=True`` (the reference's default) raises ``NotImplementedError``: only the
-  Adam branch, the path the benchmark names, is built so far;
 * hand / face parameters of ``SMPLHData`` / ``SMPLXData`` inputs are carried through
   unchanged (the fused kernel fits the 24-joint SMPL tree);
 * vertex-selected joints (model joint index >= 24) cannot be fitted yet
@@ -90,10 +94,6 @@ class WorldSpaceFitter:
         """
         if init_params.transl is None:
             raise ValueError("init_params.transl must be provided")
-        if self.use_lbfgs:
-            raise NotImplementedError(
-                "use_lbfgs=True: the HIP engine implements the Adam branch of WorldSpaceFitter only; "
-                "set FrameOptimizeConfig(use_lbfgs=False)")
         j3d = torch.as_tensor(j3d, dtype=torch.float32)
         if j3d.dim() != 3 or j3d.shape[2] != 3:
             raise ValueError(f"j3d must be (B,K,3), got {tuple(j3d.shape)}")
@@ -132,10 +132,57 @@ class WorldSpaceFitter:
 
         cfg = self._config(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
                            per_frame_conf and conf is not None and conf.dim() == 2)
-        out = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, go, bp, be, tr)
+        if self.use_lbfgs:
+            out = self._fit_lbfgs(cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas)
+        else:
+            out = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, go, bp, be, tr)
         joints, verts = self.smpl.native.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"],
                                              want_vertices=want_vertices)
         return out, joints, verts, out["loss"]
+
+    def _fit_lbfgs(self, cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas):
+        """LBFGS branch (world_space.py:231-247): ``torch.optim.LBFGS(params, max_iter=num_iters,
+        lr=step_size, line_search_fn="strong_wolfe").step(closure)`` per frame, with the closure's
+        loss and gradient evaluated by the HIP kernel; final loss re-evaluated afterwards."""
+        max_iter = int(cfg.num_iters)
+        cfg.num_iters, cfg.step_size = 1, 0.0          # evaluate-only launches
+        B, D = go.shape[0], bp.shape[1]
+        NB = be.shape[1]
+        preserve = bp.clone()                          # world_space.py:159
+        outs = {k: [] for k in ("global_orient", "body_pose", "betas", "transl", "loss")}
+        for f in range(B):
+            sl = slice(f, f + 1)
+            p = [go[sl].clone().requires_grad_(True), bp[sl].clone().requires_grad_(True),
+                 tr[sl].clone().requires_grad_(True)]
+            beta = be[sl].clone()
+            if not freeze_betas:
+                beta.requires_grad_(True)
+                p.append(beta)                         # parameter order of world_space.py:215-229
+            cf = conf[sl].contiguous() if (conf is not None and conf.dim() == 2) else conf
+            pres = preserve[sl].contiguous()
+
+            def evaluate(want_grad):
+                with torch.no_grad():
+                    return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt[sl].contiguous(),
+                                            cf, p[0].detach().contiguous(), p[1].detach().contiguous(),
+                                            beta.detach().contiguous(), p[2].detach().contiguous(),
+                                            preserve_pose=pres, want_grad=want_grad)
+
+            def closure():
+                r = evaluate(True)
+                g = r["grad"]
+                p[0].grad = g[:, 0:3].clone()
+                p[1].grad = g[:, 3:3 + D].clone()
+                p[2].grad = g[:, 3 + D + NB:].clone()
+                if not freeze_betas:
+                    beta.grad = g[:, 3 + D:3 + D + NB].clone()
+                return r["loss"].sum()
+
+            torch.optim.LBFGS(p, max_iter=max_iter, lr=float(self.step_size), line_search_fn="strong_wolfe").step(closure)
+            final = evaluate(False)                    # world_space.py:245-246
+            outs["global_orient"].append(p[0].detach()); outs["body_pose"].append(p[1].detach())
+            outs["transl"].append(p[2].detach()); outs["betas"].append(beta.detach()); outs["loss"].append(final["loss"])
+        return {k: torch.cat(v, dim=0).contiguous() for k, v in outs.items()}
 
     def fit_frame(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
                   seq_ind: int = 0, target_model_indices: Optional[torch.Tensor] = None,

@@ -258,3 +258,70 @@ def fit_camera_adam_one(model, prior: GMMPrior, global_orient, body_pose, betas,
     res.stage1 = stage1
     res.init_cam_t = t0
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# LBFGS branch of the world fitter (reference core/fitters/world_space.py:231-247) and the
+# multi-frame shape pre-pass (reference core/shape.py:10-115).  Pinned by
+# tests/golden/lbfgs_world_*.npz and tests/golden/shape_pass.npz.
+# ---------------------------------------------------------------------------------------------
+def fit_world_lbfgs_one(model, prior: GMMPrior, global_orient, body_pose, betas, transl, j3d, conf=None, *,
+                        max_iter: int, lr: float = 1e-2, seq_ind: int = 0, freeze_betas: bool = False,
+                        weights: Optional[FitWeights] = None, model_idx: Optional[Sequence[int]] = None) -> FitOutput:
+    """One frame: ``torch.optim.LBFGS(params, max_iter, lr, strong_wolfe).step(closure)``, then the
+    loss at the result."""
+    w = weights or FitWeights()
+    go = global_orient.clone().detach().requires_grad_(True)
+    bp = body_pose.clone().detach().requires_grad_(True)
+    tr = transl.clone().detach().requires_grad_(True)
+    be = betas.clone().detach()
+    be.requires_grad = not freeze_betas
+    preserve = bp.clone().detach()
+    K = j3d.shape[1]
+    conf = torch.ones(K) if conf is None else conf
+    idx = list(range(K)) if model_idx is None else list(model_idx)
+
+    def total():
+        out = model(global_orient=go, body_pose=bp, betas=be, transl=tr)
+        return frame_losses(bp, preserve, be, out.joints[:, idx, :], j3d, prior, conf, w, preserve_on=seq_ind > 0).sum()
+
+    params = [go, bp, tr] + ([] if freeze_betas else [be])
+    opt = torch.optim.LBFGS(params, max_iter=max_iter, lr=lr, line_search_fn="strong_wolfe")
+
+    def closure():
+        opt.zero_grad()
+        loss = total()
+        loss.backward()
+        return loss
+
+    opt.step(closure)
+    with torch.no_grad():
+        final = total()
+        out = model(global_orient=go, body_pose=bp, betas=be, transl=tr, return_full_pose=False)
+    return FitOutput(go.detach(), bp.detach(), be.detach(), tr.detach(), out.joints.detach(), out.vertices.detach(),
+                     final.detach().reshape(1))
+
+
+def shape_pass_lbfgs(model, init_betas, pose_init, j3d_world, conf, frame_indices, *, num_iters: int = 40,
+                     step_size: float = 1e-1, shape_prior_weight: float = 5.0, model_idx=None, root: int = 0):
+    """Shared betas over several frames (shape.py:66-105, LBFGS branch): per frame the model is
+    root-aligned to the target and the squared joint error plus ``w_s^2 |beta|^2`` is added."""
+    betas = init_betas.clone().detach().requires_grad_(True)
+    K = j3d_world.shape[1]
+    idx = list(range(K)) if model_idx is None else list(model_idx)
+    opt = torch.optim.LBFGS([betas], max_iter=num_iters, lr=step_size, line_search_fn="strong_wolfe")
+
+    def closure():
+        opt.zero_grad()
+        total = betas.new_tensor(0.0)
+        for t in frame_indices:
+            pose_t = pose_init[t:t + 1]
+            joints = model(global_orient=pose_t[:, :3], body_pose=pose_t[:, 3:], betas=betas).joints
+            transl_t = j3d_world[t:t + 1, root, :] - joints[:, root, :]
+            err = (joints + transl_t.unsqueeze(1))[:, idx, :] - j3d_world[t:t + 1]
+            total = total + ((conf ** 2) * (err ** 2).sum(dim=-1)).sum() + (shape_prior_weight ** 2) * (betas ** 2).sum()
+        total.backward()
+        return total
+
+    opt.step(closure)
+    return betas.detach()

@@ -316,6 +316,50 @@ def main():
             out_verts_sampled=cat(outs["verts_sampled"]), sampled_vertex_ids=sample_vertex_ids(6890))
         print(f"[golden] camera {name}: iters={iters} losses={cat(outs['loss'])}")
 
+    # ---- LBFGS branch of the world fitter (the reference's default) --------------------------------------
+    WorldSpaceFitter = ref[0]
+    for name, seq_ind, iters, freeze in (("first", 0, 30, False), ("followup", 4, 10, False), ("frozen", 0, 15, True)):
+        fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=iters, num_iters_followup=iters,
+                                  use_lbfgs=True, joints_category="AMASS", device=torch.device("cpu"))
+        src_init = init3 if seq_ind == 0 else warm
+        outs = {k: [] for k in ("go", "bp", "be", "tr", "loss", "joints")}
+        n = 3
+        for i in range(n):
+            sl = slice(i, i + 1)
+            res = fitter.fit_frame(SMPLData(betas=src_init["betas"][sl], global_orient=src_init["global_orient"][sl],
+                                            body_pose=src_init["body_pose"][sl], transl=src_init["transl"][sl]),
+                                   noisy22[sl], conf_3d=conf, seq_ind=seq_ind, joint_loss_weight=600.0,
+                                   pose_preserve_weight=5.0, freeze_betas=freeze)
+            p = res.params
+            outs["go"].append(p.global_orient); outs["bp"].append(p.body_pose); outs["be"].append(p.betas)
+            outs["tr"].append(p.transl); outs["loss"].append(res.loss.reshape(1)); outs["joints"].append(res.joints)
+        cat = lambda xs: torch.cat(xs, dim=0).detach().numpy()
+        np.savez_compressed(
+            GOLDEN / f"lbfgs_world_{name}.npz", case=name, seq_ind=seq_ind, max_iter=iters, freeze_betas=int(freeze),
+            conf=conf.numpy(), j3d=noisy22[:n].numpy(),
+            init_global_orient=src_init["global_orient"][:n].numpy(), init_body_pose=src_init["body_pose"][:n].numpy(),
+            init_betas=src_init["betas"][:n].numpy(), init_transl=src_init["transl"][:n].numpy(),
+            out_global_orient=cat(outs["go"]), out_body_pose=cat(outs["bp"]), out_betas=cat(outs["be"]),
+            out_transl=cat(outs["tr"]), out_loss=cat(outs["loss"]), out_joints=cat(outs["joints"]))
+        print(f"[golden] lbfgs {name}: losses={cat(outs['loss'])}")
+
+    # ---- multi-frame shape pre-pass (reference core/shape.py, LBFGS branch) ------------------------------
+    from keypoints2body.core.shape import optimize_shape_multi_frame  # type: ignore
+    Tn = 6
+    # a sequence the pass can explain: every frame at the mean pose, one common body shape, own translation
+    with torch.no_grad():
+        true_betas = tt(poses.betas[:1]).repeat(Tn, 1)
+        seq = model(global_orient=mean_pose[:Tn, :3], body_pose=mean_pose[:Tn, 3:], betas=true_betas,
+                    transl=tt(poses.transl[:Tn])).joints[:, :22] + tt(synthetic.target_noise(Tn, 22, seed=5, scale=0.002))
+    betas_opt = optimize_shape_multi_frame(model, init_betas=mean_shape[:1], pose_init=mean_pose[:Tn], j3d_world=seq,
+                                           joints_category="AMASS", num_iters=40, step_size=1e-1, use_lbfgs=True,
+                                           device=torch.device("cpu"), frame_indices=list(range(4)),
+                                           joints3d_conf=conf, shape_prior_weight=5.0)
+    np.savez_compressed(GOLDEN / "shape_pass.npz", j3d=seq.numpy(), conf=conf.numpy(), mean_pose=mean_pose[:1].numpy(),
+                        init_betas=mean_shape[:1].numpy(), num_shape_frames=4, num_shape_iters=40,
+                        true_betas=true_betas[:1].numpy(), out_betas=betas_opt.numpy())
+    print("[golden] shape pass betas:", betas_opt.numpy().round(4))
+
     print("golden fixtures written to", GOLDEN)
 
 
