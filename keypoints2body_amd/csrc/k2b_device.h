@@ -54,22 +54,46 @@ __device__ __forceinline__ float read_lane(float v, int lane) {  // lane must be
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32): the IEEE-exact division and
+// sqrt sequences cost ~10 dependent instructions each, and this kernel is latency-bound.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// sin and cos of a non-negative angle with ONE shared range reduction (k = round(a 2/pi), two-term
+// Cody-Waite) and the fdlibm float kernels on [-pi/4, pi/4]; ~1-2 ulp.  Rotation angles are O(1);
+// beyond 1e3 rad the two-term reduction loses accuracy and the library functions take over.
+__device__ __forceinline__ void sincos_small(float a, float& s, float& c) {
+    if (a > 1.0e3f) { s = sinf(a); c = cosf(a); return; }
+    const float kf = rintf(a * 0.63661977236758134308f);
+    const int k = (int)kf;
+    float r = fmaf(kf, -1.57079625129699707031f, a);      // pi/2 high part
+    r = fmaf(kf, -7.54978941586159635335e-08f, r);        // pi/2 low part
+    const float z = r * r;
+    const float ps = r + r * z * (-0.166666666416265235595f + z * (0.0083333293858894631756f +
+                     z * (-0.000198393348360966317347f + z * 0.0000027183114939898219064f)));
+    const float pc = 1.0f + z * (-0.499999997251031003120f + z * (0.0416666233237390631894f +
+                     z * (-0.00138867637746099294692f + z * 0.0000243904487962774090654f)));
+    const float s0 = (k & 1) ? pc : ps, c0 = (k & 1) ? ps : pc;
+    s = (k & 2) ? -s0 : s0;
+    c = ((k + 1) & 2) ? -c0 : c0;
+}
+
 // Rodrigues' formula exactly as smplx.lbs.batch_rodrigues evaluates it
 // (oracle/smpl_torch.py::batch_rodrigues): angle = ||theta + 1e-8||, u = theta / angle,
 // R = I + sin(angle) K + (1 - cos(angle)) K K with K = skew(u).
 struct Rodrigues {
     Mat3 R;
     Vec3 u;
-    float angle, s, c;
+    float angle, inv_angle, s, c;
 };
 
 __device__ __forceinline__ Rodrigues rodrigues_fwd(Vec3 th) {
     Rodrigues o;
     const float ex = th.x + 1e-8f, ey = th.y + 1e-8f, ez = th.z + 1e-8f;
-    o.angle = sqrtf(ex * ex + ey * ey + ez * ez);
-    o.u = {th.x / o.angle, th.y / o.angle, th.z / o.angle};
-    o.s = sinf(o.angle);
-    o.c = cosf(o.angle);
+    o.angle = fast_sqrt(ex * ex + ey * ey + ez * ez);
+    o.inv_angle = fast_rcp(o.angle);
+    o.u = {th.x * o.inv_angle, th.y * o.inv_angle, th.z * o.inv_angle};
+    sincos_small(o.angle, o.s, o.c);
     const float omc = 1.0f - o.c;
     const float ux = o.u.x, uy = o.u.y, uz = o.u.z;
     // K K = u u^T - (u.u) I restricted to what the matrix product gives
@@ -107,10 +131,10 @@ __device__ __forceinline__ Vec3 rodrigues_bwd(const Rodrigues& f, Vec3 th, const
 #pragma unroll
     for (int i = 0; i < 9; ++i) H.m[i] = f.s * G.m[i] - omc * (GK.m[i] + KG.m[i]);
     const Vec3 g_u = {H.m[7] - H.m[5], H.m[2] - H.m[6], H.m[3] - H.m[1]};
-    const float a = f.angle;
-    const float g_a = f.c * g_s + f.s * g_omc - (g_u.x * th.x + g_u.y * th.y + g_u.z * th.z) / (a * a);
-    return {g_u.x / a + g_a * (th.x + 1e-8f) / a, g_u.y / a + g_a * (th.y + 1e-8f) / a,
-            g_u.z / a + g_a * (th.z + 1e-8f) / a};
+    const float ia = f.inv_angle;
+    const float g_a = f.c * g_s + f.s * g_omc - (g_u.x * th.x + g_u.y * th.y + g_u.z * th.z) * (ia * ia);
+    return {(g_u.x + g_a * (th.x + 1e-8f)) * ia, (g_u.y + g_a * (th.y + 1e-8f)) * ia,
+            (g_u.z + g_a * (th.z + 1e-8f)) * ia};
 }
 
 }  // namespace k2b

@@ -48,14 +48,14 @@ namespace k2b {
 // library is built without it: no stamp executes there.
 #ifdef K2B_FIT_STAMPS
 __device__ unsigned long long* g_k2b_stamps = nullptr;
+// stamps stay in registers during the iteration and are stored once after the loop, so that a stamp
+// costs one s_memtime + lgkmcnt wait and no memory traffic
 #define K2B_STAMP(i)                                                                         \
     do {                                                                                     \
         if (stamp_on) {                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                               \
-            unsigned long long t__;                                                          \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_reg[i])::"memory"); \
             __builtin_amdgcn_sched_barrier(0);                                               \
-            if (lane == 0) g_k2b_stamps[i] = t__;                                            \
         }                                                                                    \
     } while (0)
 #else
@@ -274,11 +274,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 
     float loss_total = 0.f;
     float g0 = 0.f, g1 = 0.f;
+#ifdef K2B_FIT_STAMPS
+    unsigned long long stamp_reg[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     for (int it = 0; it < a.num_iters; ++it) {
         const bool last = it == a.num_iters - 1;
 #ifdef K2B_FIT_STAMPS
-        const bool stamp_on = (it == 5) && blockIdx.x == 0 && wave == 0 && g_k2b_stamps != nullptr;
+        const bool stamp_on = (it == 5) && blockIdx.x == 0 && (wave >> 1) == 0;   // wave 0 (row) and wave 1 (tree, split mode)
 #endif
         K2B_STAMP(0);
         // ---- a. parameters -> staging strip ------------------------------------------------
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             if (last) part = wconf * ((s2 * x2) / dx + (s2 * y2) / dy + (s2 * z2) / dz);
             // d gmof / d e = 2 e s^4 / (s^2 + e^2)^2
             const float k2 = 2.f * wconf * (s2 * s2);
-            gj = {k2 * ex / (dx * dx), k2 * ey / (dy * dy), k2 * ez / (dz * dz)};
+            gj = {k2 * ex * fast_rcp(dx * dx), k2 * ey * fast_rcp(dy * dy), k2 * ez * fast_rcp(dz * dz)};
         }
         K2B_STAMP(7);
         // subtree sums of g and p x g: a subtree is the lane range [t, t + size_t), summed as
@@ -557,21 +560,26 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         K2B_STAMP(11);
         // ---- g. Adam (torch.optim.Adam, single-tensor path) ------------------------------------------
         const float2 co = a.adam_coef[it];     // {lr / (1 - b1^t), sqrt(1 - b2^t)}
+        const float inv_bc2 = fast_rcp(co.y);
         if (optA) {
             m0 = m0 + om_b1 * (g0 - m0);
             v0 = v0 * a.beta2 + om_b2 * g0 * g0;
-            const float denom = sqrtf(v0) / co.y + a.eps;
-            x0 = x0 - co.x * (m0 / denom);
+            const float denom = fast_sqrt(v0) * inv_bc2 + a.eps;
+            x0 = x0 - co.x * (m0 * fast_rcp(denom));
         }
         if (optB) {
             m1 = m1 + om_b1 * (g1 - m1);
             v1 = v1 * a.beta2 + om_b2 * g1 * g1;
-            const float denom = sqrtf(v1) / co.y + a.eps;
-            x1 = x1 - co.x * (m1 / denom);
+            const float denom = fast_sqrt(v1) * inv_bc2 + a.eps;
+            x1 = x1 - co.x * (m1 * fast_rcp(denom));
         }
         }  // do_row
         K2B_STAMP(12);
     }
+#ifdef K2B_FIT_STAMPS
+    if (blockIdx.x == 0 && (wave >> 1) == 0 && lane == 0 && g_k2b_stamps != nullptr)
+        for (int i = 0; i < 13; ++i) g_k2b_stamps[wave * 16 + i] = stamp_reg[i];
+#endif
     if (!do_row || !f_valid) return;
 
     // ---- 4. results -----------------------------------------------------------------------------------

@@ -22,11 +22,14 @@ cfg = native.default_fit_config(); cfg.num_iters = 20
 for _ in range(3):
     native.fit_world(m, pr, cfg, list(range(22)), j3d, None, z(B, 3), z(B, 69), z(B, 10), j3d[:, 0].contiguous())
 torch.cuda.synchronize()
-s = stamps.cpu().numpy()[:13]
-names = ["a/b staging+reads", "GMM A-pass (LDS)", "GMM B rows (global)", "butterflies+argmin", "J(beta)+Rodrigues fwd",
-         "chain down-sweep", "joint loss+grad", "up-sweep", "torque+Rodrigues bwd", "beta grad butterfly",
-         "transpose+priors", "Adam"]
-d = np.diff(s)
-print("total cycles/iter (stamped build):", s[12] - s[0])
-for n, c in zip(names, d):
-    print(f"  {n:28s} {c:7d}  {100.0 * c / (s[12] - s[0]):5.1f}%")
+names = ["a staging write+sync", "GMM A-pass (LDS)", "GMM B rows", "butterflies+argmin", "J(beta)+Rodrigues fwd",
+         "doubling down-sweep", "joint loss+grad", "windowed subtree sums", "torque+Rodrigues bwd", "beta grad butterfly",
+         "grad strip write / sync / priors", "Adam"]
+raw = stamps.cpu().numpy()
+for w, role in ((0, "wave 0 (row wave in split mode / the only wave in unified mode)"), (1, "wave 1 (tree wave in split mode)")):
+    s = raw[w * 16: w * 16 + 13]
+    if s[12] == 0: continue
+    d = np.diff(s)
+    print(role, "- total cycles/iter:", s[12] - s[0])
+    for n, c in zip(names, d):
+        print(f"  {n:34s} {c:7d}  {100.0 * c / max(1, (s[12] - s[0])):5.1f}%")
