@@ -68,7 +68,7 @@ struct k2b_model {
     std::string fit_why;
     float *dt = nullptr, *dd = nullptr;
     int* tree = nullptr;
-    int num_rounds = 0, num_win_bits = 0;
+    std::vector<int> depth;                                  // depth of every joint (root 0)
     // LBS B operands (f16 hi/lo, MFMA fragment order) for the whole mesh and for the E extra-joint vertices
     struct VertexSet {
         k2b::k2b_half *pdh = nullptr, *pdl = nullptr, *wth = nullptr, *wtl = nullptr;
@@ -245,12 +245,10 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         }
         for (int j = J - 1; j >= 1; --j) size[parents[j]] += size[j];
     }
-    int rounds = 0, bits = 0;
+    int rounds = 0;
     while ((1 << rounds) < maxd + 1) ++rounds;
-    while ((1 << bits) <= J) ++bits;
-    if (ok && (rounds > k2b::kMaxRounds || bits > k2b::kMaxWinBits)) { ok = false; m->fit_why = "tree too deep / large for the fused fit kernel"; }
-    m->num_rounds = rounds;
-    m->num_win_bits = bits;
+    if (ok && (rounds > k2b::kMaxRounds || J > 32)) { ok = false; m->fit_why = "tree too deep / large for the fused fit kernel"; }
+    m->depth = depth;
     std::vector<int> tab((size_t)64 * k2b::kLaneTabStride, -1);
     std::vector<float> dt((size_t)64 * 3, 0.f), dd((size_t)64 * 3 * k2b::kMaxBetas, 0.f);
     if (ok) {
@@ -268,10 +266,8 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                     anc = parents[aj] >= 0 ? lane_of[parents[aj]] : -1;
                 }
             }
-            // subtree [l, l + size) as power-of-two windows, largest first
-            int off = 0;
-            for (int b = k2b::kMaxWinBits - 1; b >= 0; --b)
-                if (size[j] & (1 << b)) { t[2 + k2b::kMaxRounds + b] = l + off; off += 1 << b; }
+            t[2 + k2b::kMaxRounds] = size[j];        // subtree = lanes [l, l + size)
+            t[3 + k2b::kMaxRounds] = depth[j];
             for (int c = 0; c < 3; ++c) {
                 dt[l * 3 + c] = m->h_j_template[j * 3 + c] - (p >= 0 ? m->h_j_template[p * 3 + c] : 0.f);
                 for (int k = 0; k < NB; ++k)
@@ -454,7 +450,15 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     }
 
     a.dt = model->dt; a.dd = model->dd; a.lane_tab = model->tree;
-    a.num_rounds = model->num_rounds; a.num_win_bits = model->num_win_bits; a.num_betas = model->NB;
+    // global transforms are only needed down to the deepest targeted joint: 2^rounds > its depth
+    {
+        int maxd = 0;
+        for (int k = 0; k < K; ++k) maxd = model->depth[model_joint_index[k]] > maxd ? model->depth[model_joint_index[k]] : maxd;
+        int rounds = 0;
+        while ((1 << rounds) < maxd + 1) ++rounds;
+        a.num_rounds = rounds;
+    }
+    a.num_betas = model->NB;
     a.pa_image = prior->pa_image; a.row_const = prior->row_const; a.neg_log_nllw = prior->nlw;
     a.num_gauss = prior->M;
     a.num_frames = B; a.num_targets = K;

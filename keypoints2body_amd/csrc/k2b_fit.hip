@@ -76,6 +76,36 @@ constexpr int XS_BODY = 4, XS_BETA = 76, XS_TRANSL = 92;
 static_assert(P_FLOATS == kPriorImageFloats, "host image size");
 static_assert((P_FLOATS + MAXW * XS) * 4 <= 163840, "LDS budget");
 
+// Inclusive prefix sum inside each 32-lane half with DPP (no LDS traffic): Hillis-Steele inside each
+// row of 16 (row_shr 1, 2, 4, 8; out-of-row sources read 0), then row_bcast:15 into rows 1 and 3.
+// Accumulated in DOUBLE: the subtree sums are differences of two prefixes, and in fp32 their
+// absolute error (eps x the largest prefix) was visible after Adam's per-parameter normalisation
+// (parity 3e-6 -> up to 9e-5); in double the differences are exact to fp32.
+__device__ __forceinline__ double half_wave_inclusive_scan(float v) {
+    double s = (double)v;
+#define K2B_DPP_ADD64(ctrl, row_mask)                                                                   \
+    {                                                                                                   \
+        const long long bits = __builtin_bit_cast(long long, s);                                        \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), ctrl, row_mask, 0xf, true); \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, row_mask, 0xf, true);    \
+        s += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);                      \
+    }
+    K2B_DPP_ADD64(0x111, 0xf);   // row_shr:1
+    K2B_DPP_ADD64(0x112, 0xf);   // row_shr:2
+    K2B_DPP_ADD64(0x114, 0xf);   // row_shr:4
+    K2B_DPP_ADD64(0x118, 0xf);   // row_shr:8
+    K2B_DPP_ADD64(0x142, 0xa);   // row_bcast:15 -> rows 1, 3 (lanes 16..31 and 48..63)
+#undef K2B_DPP_ADD64
+    return s;
+}
+
+__device__ __forceinline__ double bperm64(int byte_addr, double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(bits & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(bits >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ float bperm(int byte_addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
@@ -153,10 +183,13 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     __syncthreads();
 
     // frame and role of this wave
+    // (split: waves 0..F-1 are the row waves of frames 0..F-1, waves F..2F-1 their tree waves.  Waves w
+    //  and w + 4 of a workgroup share a SIMD, so with F = 4 every SIMD hosts one row wave and one tree
+    //  wave - complementary instruction mixes - instead of two of a kind.)
     const int frames_per_wg = SPLIT ? waves >> 1 : waves;
-    const int fslot = SPLIT ? wave >> 1 : wave;
-    const bool do_row = !SPLIT || (wave & 1) == 0;    // GMM prior, priors in row layout, Adam, results
-    const bool do_tree = !SPLIT || (wave & 1) == 1;   // kinematics, joint loss, analytic backward
+    const int fslot = SPLIT ? (wave < frames_per_wg ? wave : wave - frames_per_wg) : wave;
+    const bool do_row = !SPLIT || wave < frames_per_wg;     // GMM prior, priors in row layout, Adam, results
+    const bool do_tree = !SPLIT || wave >= frames_per_wg;   // kinematics, joint loss, analytic backward
     const int f_raw = blockIdx.x * frames_per_wg + fslot;
     if (!SPLIT && f_raw >= a.num_frames) return;      // unified: no further workgroup-wide sync below
     // split: waves of a padding slot must still reach every barrier; they recompute the last frame
@@ -206,7 +239,6 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const int* lt = a.lane_tab + lane * kLaneTabStride;
     const int joint = lt[0];                    // joint of this lane, -1 beyond the tree
     const bool isJ = joint >= 0;
-    const int par_addr = (lt[1] >= 0 ? lt[1] : lane) * 4;
     const bool has_par = lt[1] >= 0;
     int anc_addr[kMaxRounds];
     bool anc_ok[kMaxRounds];
@@ -215,17 +247,17 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         anc_ok[r] = lt[2 + r] >= 0;
         anc_addr[r] = (anc_ok[r] ? lt[2 + r] : lane) * 4;
     }
-    // the same windows for the upper half-wave (lane 32 + t mirrors lane t, sources shifted by 32 lanes)
-    int win_addr_h[kMaxWinBits];
-    bool win_ok_h[kMaxWinBits];
+    // subtree lane range of this lane's joint, mirrored into the upper half-wave (lane 32 + t)
+    bool sub_ok, sub_has_pre;
+    int sub_end_addr, sub_pre_addr;
     {
         const int* lt2 = a.lane_tab + (lane & 31) * kLaneTabStride;
-#pragma unroll
-        for (int b = 0; b < kMaxWinBits; ++b) {
-            const int src = lt2[2 + kMaxRounds + b];
-            win_ok_h[b] = src >= 0;
-            win_addr_h[b] = (src >= 0 ? src + (lane & 32) : lane) * 4;
-        }
+        const int t = lane & 31, size = lt2[2 + kMaxRounds];      // subtree size in lanes (0 beyond the tree)
+        sub_ok = lt2[0] >= 0 && size > 0;
+        const int first = (lane & 32) + t, lastl = first + (sub_ok ? size - 1 : 0);
+        sub_has_pre = t > 0;                                       // the scan restarts at lanes 0 and 32
+        sub_end_addr = lastl * 4;
+        sub_pre_addr = (sub_has_pre ? first - 1 : first) * 4;
     }
     float dt[3], dd[3][NBT];
 #pragma unroll
@@ -281,7 +313,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     for (int it = 0; it < a.num_iters; ++it) {
         const bool last = it == a.num_iters - 1;
 #ifdef K2B_FIT_STAMPS
-        const bool stamp_on = (it == 5) && blockIdx.x == 0 && (wave >> 1) == 0;   // wave 0 (row) and wave 1 (tree, split mode)
+        const bool stamp_on = (it == 5) && blockIdx.x == 0 && fslot == 0;   // frame slot 0: its row wave and, in split mode, its tree wave
 #endif
         K2B_STAMP(0);
         // ---- a. parameters -> staging strip ------------------------------------------------
@@ -422,11 +454,18 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 }
             }
         }
-        Mat3 Rgp;                          // parent's global rotation (identity at the root)
+        // parent's global rotation without cross-lane traffic: Rg = Rgp R  =>  Rgp = Rg R^T
+        // (identity at the root; lanes beyond the needed depth hold unused values)
+        Mat3 Rgp;
+        {
+            const float* R = rod.R.m;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const float v = bperm(par_addr, Rg.m[i]);
-            Rgp.m[i] = has_par ? v : ((i % 4 == 0) ? 1.f : 0.f);
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = Rg.m[3 * r] * R[3 * c] + Rg.m[3 * r + 1] * R[3 * c + 1] + Rg.m[3 * r + 2] * R[3 * c + 2];
+                    Rgp.m[3 * r + c] = has_par ? v : ((r == c) ? 1.f : 0.f);
+                }
         }
 
         K2B_STAMP(6);
@@ -443,9 +482,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             gj = {k2 * ex * fast_rcp(dx * dx), k2 * ey * fast_rcp(dy * dy), k2 * ez * fast_rcp(dz * dz)};
         }
         K2B_STAMP(7);
-        // subtree sums of g and p x g: a subtree is the lane range [t, t + size_t), summed as
-        // power-of-two windows W_b[x] = sum of lanes x .. x + 2^b - 1.  The two triples ride in the
-        // two 32-lane halves (g in lanes t, p x g in lanes 32 + t), so one cross-lane move serves both.
+        // subtree sums of g and p x g.  A subtree is the lane range [t, t + size_t) (DFS order), so its
+        // sum is a difference of two inclusive prefix sums.  The two triples ride in the two 32-lane
+        // halves (g in lanes t, p x g in lanes 32 + t); the scan is five DPP steps per half-wave in
+        // double (no LDS round trip), then ONE round of cross-lane fetches for the range ends.
         float sums[6];
         {
             const Vec3 pxg = cross(pj, gj);
@@ -461,30 +501,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                     w3[i] = up_half ? moved : lo[i];
                 }
             }
-            const int half_off = up_half ? 128 : 0;                 // byte offset of the upper half's lanes
             float s3[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float t = bperm(win_addr_h[0], w3[i]);
-                s3[i] = win_ok_h[0] ? t : 0.f;
+                const double scan = half_wave_inclusive_scan(w3[i]);
+                const double hi_end = bperm64(sub_end_addr, scan);  // prefix at the last lane of the subtree
+                const double lo_end = bperm64(sub_pre_addr, scan);  // prefix just before its first lane
+                s3[i] = sub_ok ? (float)(hi_end - (sub_has_pre ? lo_end : 0.0)) : 0.f;
             }
-#pragma unroll
-            for (int b = 1; b < kMaxWinBits; ++b) {
-                if (b < a.num_win_bits) {
-                    const int dn = ((lane + (1 << (b - 1))) & 63) * 4;
-                    float up[3];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) up[i] = bperm(dn, w3[i]);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) w3[i] += up[i];                    // W_b
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const float t = bperm(win_addr_h[b], w3[i]);
-                        s3[i] += win_ok_h[b] ? t : 0.f;
-                    }
-                }
-            }
-            (void)half_off;
             // bring the p x g sums back to the joint's own lane
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         if (bodyA) {
             g0 += wpp2 * yA + 2.f * wpr2 * (x0 - pr0);
             if (angA != 0.f) {
-                const float e = expf(x0 * angA);
+                const float e = __expf(x0 * angA);
                 g0 += wa2 * 2.f * angA * e * e;
                 if (last) part += wa2 * e * e;
             }
@@ -577,8 +601,8 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         K2B_STAMP(12);
     }
 #ifdef K2B_FIT_STAMPS
-    if (blockIdx.x == 0 && (wave >> 1) == 0 && lane == 0 && g_k2b_stamps != nullptr)
-        for (int i = 0; i < 13; ++i) g_k2b_stamps[wave * 16 + i] = stamp_reg[i];
+    if (blockIdx.x == 0 && fslot == 0 && lane == 0 && g_k2b_stamps != nullptr)
+        for (int i = 0; i < 13; ++i) g_k2b_stamps[(do_row ? 0 : 1) * 16 + i] = stamp_reg[i];
 #endif
     if (!do_row || !f_valid) return;
 

@@ -14,8 +14,7 @@ constexpr int kMaxBetas = 16;
 constexpr int kFitMaxWaves = 8;     // frames (waves) per workgroup
 constexpr int kMaxJoints = 64;
 constexpr int kMaxRounds = 4;       // pointer-doubling rounds: tree depth < 2^4
-constexpr int kMaxWinBits = 5;      // subtree sizes < 2^5
-constexpr int kLaneTabStride = 16;  // ints per lane: joint, parent lane, anc[kMaxRounds], win[kMaxWinBits]
+constexpr int kLaneTabStride = 8;   // ints per lane: joint, parent lane, anc[kMaxRounds], subtree size, depth
 // LDS image of the prior: rows 0..60 as [8][17][64][4] + [8][64], rows 61..68 as [8][9][64]
 constexpr int kPriorImageFloats = kPriorMaxGauss * (17 * 256 + 64) + kPriorMaxGauss * 9 * 64;
 
@@ -26,7 +25,7 @@ struct FitArgs {
     const float* dt;            // [64][3]     J_template[j] - J_template[parent]  (root: J_template[0])
     const float* dd;            // [64][3][16] same for J_dirs, zero padded
     const int* lane_tab;        // [64][kLaneTabStride]
-    int num_rounds, num_win_bits;
+    int num_rounds;             // pointer-doubling rounds needed by the targeted joints of this call
     int num_betas;
     // prior (device)
     const float* pa_image;      // LDS image, kPriorImageFloats floats (see k2b_api.hip)
