@@ -110,55 +110,89 @@ __device__ __forceinline__ float bperm(int byte_addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
 
+// ---- LDS-free cross-lane exchanges (gfx950) ------------------------------------------------------
+// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
+// (Inline asm: the clang builtin of ROCm 7.2 returns the updated first register in BOTH result
+//  elements - tools/probe/lanes.hip.  The s_nop covers the VALU-write -> cross-lane-read wait states
+//  hipcc does not insert inside asm.)
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// v_permlane16_swap: the odd 16-lane rows of `a` trade places with the even rows of `b`.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp<0xB1>(v); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp<0x4E>(v); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor8(float v) { return dpp<0x128>(v); }   // row_ror:8
+__device__ __forceinline__ float lane_xor4(float v) {                           // row_shr:4 into banks 1,3 ; row_shl:4 into banks 0,2
+    const int x = __builtin_bit_cast(int, v);
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xa, true);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, x, 0x104, 0xf, 0x5, true));
+}
+// sum of v over the lane and its partner lane ^ 32 / ^ 16 (every lane gets the pair sum)
+__device__ __forceinline__ float pair_sum32(float v) { float a = v, b = v; swap32(a, b); return a + b; }
+__device__ __forceinline__ float pair_sum16(float v) { float a = v, b = v; swap16(a, b); return a + b; }
+
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v = pair_sum32(v);
+    v = pair_sum16(v);
+    v += lane_xor8(v);
+    v += lane_xor4(v);
+    v += lane_xor2(v);
+    v += lane_xor1(v);
+    return v;
+}
+
 // 8 per-lane values -> one value per lane: lane l ends with the sum over the 8 lanes
-// {l&7 + 8 s} of v[(l>>3)&7].  7 cross-lane moves instead of 24.
+// {l&7 + 8 s} of v[(l>>3)&7].  Halving exchanges: after swap32 of (v[i], v[4+i]) the two registers
+// hold, in every lane, its own and its partner's copy of the value that lane keeps.
 __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
     float w[4], u[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float keep = b5 ? v[4 + i] : v[i];
-        const float send = b5 ? v[i] : v[4 + i];
-        w[i] = keep + __shfl_xor(send, 32, kWave);
+        float a = v[i], b = v[4 + i];
+        swap32(a, b);
+        w[i] = a + b;              // lanes < 32: v[i] summed over the pair; lanes >= 32: v[4+i]
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float keep = b4 ? w[2 + i] : w[i];
-        const float send = b4 ? w[i] : w[2 + i];
-        u[i] = keep + __shfl_xor(send, 16, kWave);
+        float a = w[i], b = w[2 + i];
+        swap16(a, b);
+        u[i] = a + b;              // even rows: w[i]; odd rows: w[2+i]
     }
-    const float keep = b3 ? u[1] : u[0];
-    const float send = b3 ? u[0] : u[1];
-    return keep + __shfl_xor(send, 8, kWave);
+    const float s0 = u[0] + lane_xor8(u[0]), s1 = u[1] + lane_xor8(u[1]);
+    return (lane & 8) ? s1 : s0;
 }
 
 // 16 per-lane values -> lane l ends with the wave-wide sum of v[(l>>2)&15].
 __device__ __forceinline__ float butterfly16_sum(const float (&v)[16], int lane) {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
     float w8[8], w4[4], w2[2];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float keep = b5 ? v[8 + i] : v[i];
-        const float send = b5 ? v[i] : v[8 + i];
-        w8[i] = keep + __shfl_xor(send, 32, kWave);
+        float a = v[i], b = v[8 + i];
+        swap32(a, b);
+        w8[i] = a + b;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float keep = b4 ? w8[4 + i] : w8[i];
-        const float send = b4 ? w8[i] : w8[4 + i];
-        w4[i] = keep + __shfl_xor(send, 16, kWave);
+        float a = w8[i], b = w8[4 + i];
+        swap16(a, b);
+        w4[i] = a + b;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float keep = b3 ? w4[2 + i] : w4[i];
-        const float send = b3 ? w4[i] : w4[2 + i];
-        w2[i] = keep + __shfl_xor(send, 8, kWave);
+        const float s0 = w4[i] + lane_xor8(w4[i]), s1 = w4[2 + i] + lane_xor8(w4[2 + i]);
+        w2[i] = (lane & 8) ? s1 : s0;
     }
-    const float keep = b2 ? w2[1] : w2[0];
-    const float send = b2 ? w2[0] : w2[1];
-    float r = keep + __shfl_xor(send, 4, kWave);
-    r += __shfl_xor(r, 2, kWave);
-    r += __shfl_xor(r, 1, kWave);
+    const float t0 = w2[0] + lane_xor4(w2[0]), t1 = w2[1] + lane_xor4(w2[1]);
+    float r = (lane & 4) ? t1 : t0;
+    r += lane_xor2(r);
+    r += lane_xor1(r);
     return r;
 }
 
@@ -248,16 +282,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         anc_addr[r] = (anc_ok[r] ? lt[2 + r] : lane) * 4;
     }
     // subtree lane range of this lane's joint, mirrored into the upper half-wave (lane 32 + t)
-    bool sub_ok, sub_has_pre;
-    int sub_end_addr, sub_pre_addr;
+    bool sub_ok;
+    int sub_end_addr;
     {
         const int* lt2 = a.lane_tab + (lane & 31) * kLaneTabStride;
         const int t = lane & 31, size = lt2[2 + kMaxRounds];      // subtree size in lanes (0 beyond the tree)
         sub_ok = lt2[0] >= 0 && size > 0;
         const int first = (lane & 32) + t, lastl = first + (sub_ok ? size - 1 : 0);
-        sub_has_pre = t > 0;                                       // the scan restarts at lanes 0 and 32
         sub_end_addr = lastl * 4;
-        sub_pre_addr = (sub_has_pre ? first - 1 : first) * 4;
     }
     float dt[3], dd[3][NBT];
 #pragma unroll
@@ -399,9 +431,9 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 #pragma unroll
         for (int m = 0; m < MG; ++m) z[m] = bodyA ? (x0 - muA[m]) * acc[m] : 0.f;
         float q = butterfly8(z, lane) + zB;                  // partial of component sB over lanes {r + 8 s}
-        q += __shfl_xor(q, 4, kWave);
-        q += __shfl_xor(q, 2, kWave);
-        q += __shfl_xor(q, 1, kWave);                        // lanes 8m..8m+7: d^T P d of component m
+        q += lane_xor4(q);
+        q += lane_xor2(q);
+        q += lane_xor1(q);                                   // lanes 8m..8m+7: d^T P d of component m
         const float val = 0.5f * q + a.neg_log_nllw[sB < M ? sB : 0];
         best = read_lane(val, 0);
         int mstar = 0;
@@ -489,16 +521,15 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         float sums[6];
         {
             const Vec3 pxg = cross(pj, gj);
-            const bool up_half = lane >= 32;
-            const int mirror = (lane ^ 32) * 4;
             float w3[3];
             {
                 const float lo[3] = {isJ ? gj.x : 0.f, isJ ? gj.y : 0.f, isJ ? gj.z : 0.f};
                 const float hi[3] = {isJ ? pxg.x : 0.f, isJ ? pxg.y : 0.f, isJ ? pxg.z : 0.f};
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const float moved = bperm(mirror, hi[i]);       // lanes 32 + t receive p x g of joint t
-                    w3[i] = up_half ? moved : lo[i];
+                    float x = lo[i], y = hi[i];
+                    swap32(x, y);                                   // x: lanes t keep g, lanes 32 + t receive p x g of joint t
+                    w3[i] = x;
                 }
             }
             float s3[3];
@@ -506,14 +537,16 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             for (int i = 0; i < 3; ++i) {
                 const double scan = half_wave_inclusive_scan(w3[i]);
                 const double hi_end = bperm64(sub_end_addr, scan);  // prefix at the last lane of the subtree
-                const double lo_end = bperm64(sub_pre_addr, scan);  // prefix just before its first lane
-                s3[i] = sub_ok ? (float)(hi_end - (sub_has_pre ? lo_end : 0.0)) : 0.f;
+                const double lo_end = scan - (double)w3[i];         // prefix just before its first lane (this lane)
+                s3[i] = sub_ok ? (float)(hi_end - lo_end) : 0.f;
             }
             // bring the p x g sums back to the joint's own lane
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
+                float x = s3[i], y = s3[i];
+                swap32(x, y);                                       // y: lanes t receive the value of lane 32 + t
                 sums[i] = s3[i];
-                sums[3 + i] = bperm(mirror, s3[i]);
+                sums[3 + i] = y;
             }
         }
         const Vec3 aj = {sums[0], sums[1], sums[2]};
@@ -543,7 +576,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 
         K2B_STAMP(10);
         // ---- f. tree layout -> gradient strip (unified: the parameter strip is reused) --------------
-        const float jloss = last ? wave_sum(part) : 0.f;
+        const float jloss = last ? wave_sum_fast(part) : 0.f;
         wave_sync();
         if (isJ) { gs[thoff] = gth.x; gs[thoff + 1] = gth.y; gs[thoff + 2] = gth.z; }
         if ((lane & 3) == 0 && (lane >> 2) < NB) gs[XS_BETA + (lane >> 2)] = gbeta;
@@ -579,7 +612,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             g1 += 2.f * wt2 * (x1 - tp1);
             if (last) part += wt2 * (x1 - tp1) * (x1 - tp1);
         }
-        if (last) loss_total = wave_sum(part) + wpp2 * best + jloss;
+        if (last) loss_total = wave_sum_fast(part) + wpp2 * best + jloss;
 
         K2B_STAMP(11);
         // ---- g. Adam (torch.optim.Adam, single-tensor path) ------------------------------------------
