@@ -15,8 +15,13 @@ constexpr int kFitMaxWaves = 8;     // frames (waves) per workgroup
 constexpr int kMaxJoints = 64;
 constexpr int kMaxRounds = 4;       // pointer-doubling rounds: tree depth < 2^4
 constexpr int kLaneTabStride = 8;   // ints per lane: joint, parent lane, anc[kMaxRounds], subtree size, depth
-// LDS image of the prior: rows 0..60 as [8][17][64][4] + [8][64], rows 61..68 as [8][9][64]
-constexpr int kPriorImageFloats = kPriorMaxGauss * (17 * 256 + 64) + kPriorMaxGauss * 9 * 64;
+// LDS image of the prior's rim rows 61..68: [8][9][64]
+constexpr int kPriorImageFloats = kPriorMaxGauss * 9 * 64;
+// rows 0..63 of every component as MFMA A fragments (f16 hi / lo, see k2b_api.hip):
+//   frag32 [m][tile 4][ks0 hi, ks1 hi, ks0 lo, ks1 lo][64 lanes][8 halfs]   (K = 0..63)
+//   frag16 [m][tile 4][hi, lo][64 lanes][4 halfs]                          (K = 64..79: cols 64..68, -P mu, 0)
+constexpr int kPriorFrag32Halfs = kPriorMaxGauss * 4 * 4 * 64 * 8;
+constexpr int kPriorFrag16Halfs = kPriorMaxGauss * 4 * 2 * 64 * 4;
 
 // Kernel arguments of the fused fit (passed by value).
 struct FitArgs {
@@ -28,10 +33,15 @@ struct FitArgs {
     int num_rounds;             // pointer-doubling rounds needed by the targeted joints of this call
     int num_betas;
     // prior (device)
-    const float* pa_image;      // LDS image, kPriorImageFloats floats (see k2b_api.hip)
-    const float* row_const;     // muA[8][64], cA[8][64], muB[64], cB[64]
+    const float* pa_image;      // LDS image of the rim rows, kPriorImageFloats floats (see k2b_api.hip)
+    const void* pa_frag32;      // kPriorFrag32Halfs f16
+    const void* pa_frag16;      // kPriorFrag16Halfs f16
+    const float* mu_core;       // [8][64] means of rows 0..63
+    const float* row_const;     // muB[64], cB[64]  (rim rows after the butterfly)
     const float* neg_log_nllw;  // [8]
+    float inv_scale[kPriorMaxGauss];  // 1 / (power-of-two scale of component m's fragments)
     int num_gauss;
+    int frames_per_wg;          // set by launch_fit_world
     // call (device unless noted)
     int num_frames, num_targets;
     int lane_target[kFitJoints];  // target index fitted by joint j, or -1
