@@ -86,8 +86,8 @@ struct k2b_model {
 
 struct k2b_prior {
     int M = 0, D = 0;
-    float *pa_image = nullptr, *row_const = nullptr, *nlw = nullptr, *mu_core = nullptr;
-    k2b::k2b_half *frag32 = nullptr, *frag16 = nullptr;
+    float *pa_image = nullptr, *row_const = nullptr, *nlw = nullptr;
+    k2b::k2b_half* frag32 = nullptr;
     float inv_scale[k2b::kPriorMaxGauss] = {};
 };
 
@@ -349,80 +349,64 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
         }
     auto P = [&](int m, int i, int j) -> float { return (float)Ps[((size_t)m * D + i) * D + j]; };
 
-    // rim rows 61..68 (vector-ALU path of the fit kernel): [m][9][64], lane (r = l & 7, s = l >> 3)
+    // LDS image: rim rows 64..68 over the core columns, then mu | c of the core rows (k2b_internal.h)
+    constexpr int NC = 64, NR = 5;
     std::vector<float> pa((size_t)k2b::kPriorImageFloats, 0.f);
-    std::vector<float> rc(128, 0.f), nlw(MG, 0.f), muc((size_t)MG * 64, 0.f);
+    float* cmu = pa.data() + 2 * NR * 64 * 4;
+    std::vector<float> rc((size_t)8 * 64, 0.f), nlw(MG, 0.f);
     for (int m = 0; m < M; ++m) {
-        for (int l = 0; l < 64; ++l) {
-            const int r = l & 7, s = l >> 3;
-            for (int cc = 0; cc < 9; ++cc) {
-                const int col = 9 * s + cc;
-                pa[((size_t)m * 9 + cc) * 64 + l] = col < D ? P(m, 61 + r, col) : 0.f;
-            }
-            muc[(size_t)m * 64 + l] = means[m * D + l];
+        for (int cc = 0; cc < NR; ++cc)
+            for (int col = 0; col < NC; ++col)
+                pa[((size_t)(2 * cc + ((col >> 2) & 1)) * 64 + 8 * m + (col >> 3)) * 4 + (col & 3)] = P(m, NC + cc, col);
+        for (int r = 0; r < NC; ++r) {
+            cmu[(size_t)m * 2 * NC + r] = means[m * D + r];
+            cmu[(size_t)m * 2 * NC + NC + r] = (float)c[(size_t)m * D + r];
+        }
+        // per-lane constants of the rim rows: lane 8m + s, s < 5 <-> row 64 + s of component m
+        for (int s = 0; s < NR; ++s) {
+            const int l = 8 * m + s;
+            for (int k = 0; k < NR; ++k) rc[(size_t)k * 64 + l] = P(m, NC + s, NC + k);
+            rc[(size_t)5 * 64 + l] = (float)c[(size_t)m * D + NC + s];
+            double kb = 0.0;
+            for (int j = 0; j < NC; ++j) kb += Ps[((size_t)m * D + NC + s) * D + j] * (double)means[m * D + j];
+            rc[(size_t)6 * 64 + l] = (float)kb;
+            rc[(size_t)7 * 64 + l] = means[m * D + NC + s];
         }
         nlw[m] = -logf(nll_weights[m]);
     }
-    for (int l = 0; l < 64; ++l) {   // rim rows after the butterfly: component s = l>>3, row 61 + (l&7)
-        const int r = l & 7, s = l >> 3;
-        if (s < M) {
-            rc[l] = means[s * D + 61 + r];
-            rc[64 + l] = (float)c[(size_t)s * D + 61 + r];
-        }
-    }
-    // rows 0..63 as MFMA A fragments (v_mfma_f32_16x16x32_f16 / 16x16x16_f16: lane l holds row l & 15,
-    // k = 8 (l >> 4) + j resp. 4 (l >> 4) + j), two f16 terms per entry, scaled by a power of two per
-    // component so that the largest entry sits near 2^13 (hi never overflows, lo stays normal for every
-    // entry that matters).  Column 69 holds -c_m = -P_m mu_m; the fit kernel feeds a constant 1 there.
-    std::vector<k2b::k2b_half> f32((size_t)k2b::kPriorFrag32Halfs, (k2b::k2b_half)0.f), f16((size_t)k2b::kPriorFrag16Halfs, (k2b::k2b_half)0.f);
+    // the 64 x 64 core as MFMA A fragments (v_mfma_f32_16x16x32_f16: lane l holds row l & 15,
+    // k = 8 (l >> 4) + j), two f16 terms per entry, scaled by a power of two per component so that the
+    // largest entry sits near 2^13 (hi never overflows, lo stays normal for every entry that matters)
+    std::vector<k2b::k2b_half> f32((size_t)k2b::kPriorFrag32Halfs, (k2b::k2b_half)0.f);
     k2b_prior* p = new k2b_prior;
     p->M = M; p->D = D;
     for (int m = 0; m < MG; ++m) p->inv_scale[m] = 1.0f;
     for (int m = 0; m < M; ++m) {
-        auto entry = [&](int row, int col) -> double {
-            if (col < D) return Ps[((size_t)m * D + row) * D + col];
-            if (col == D) return -c[(size_t)m * D + row];
-            return 0.0;
-        };
         double maxabs = 0.0;
-        for (int row = 0; row < 64; ++row)
-            for (int col = 0; col <= D; ++col) maxabs = std::max(maxabs, std::fabs(entry(row, col)));
+        for (int row = 0; row < NC; ++row)
+            for (int col = 0; col < NC; ++col) maxabs = std::max(maxabs, std::fabs(Ps[((size_t)m * D + row) * D + col]));
         int e = 0;
         if (maxabs > 0.0 && std::isfinite(maxabs)) e = 13 - (int)std::ceil(std::log2(maxabs));
         e = std::max(-100, std::min(100, e));
         const double scale = std::ldexp(1.0, e);
         p->inv_scale[m] = (float)std::ldexp(1.0, -e);
-        auto split = [&](double v, k2b::k2b_half& hi, k2b::k2b_half& lo) {
-            const float x = (float)(v * scale);
-            hi = (k2b::k2b_half)x;
-            lo = (k2b::k2b_half)(x - (float)hi);
-        };
         for (int t = 0; t < 4; ++t)
             for (int l = 0; l < 64; ++l) {
                 const int row = 16 * t + (l & 15), g = l >> 4;
                 for (int ks = 0; ks < 2; ++ks)
                     for (int j = 0; j < 8; ++j) {
-                        k2b::k2b_half hi, lo;
-                        split(entry(row, 32 * ks + 8 * g + j), hi, lo);
+                        const float x = (float)(Ps[((size_t)m * D + row) * D + 32 * ks + 8 * g + j] * scale);
+                        const k2b::k2b_half hi = (k2b::k2b_half)x;
                         f32[((((size_t)m * 4 + t) * 4 + ks) * 64 + l) * 8 + j] = hi;
-                        f32[((((size_t)m * 4 + t) * 4 + 2 + ks) * 64 + l) * 8 + j] = lo;
+                        f32[((((size_t)m * 4 + t) * 4 + 2 + ks) * 64 + l) * 8 + j] = (k2b::k2b_half)(x - (float)hi);
                     }
-                for (int j = 0; j < 4; ++j) {
-                    k2b::k2b_half hi, lo;
-                    split(entry(row, 64 + 4 * g + j), hi, lo);
-                    f16[((((size_t)m * 4 + t) * 2 + 0) * 64 + l) * 4 + j] = hi;
-                    f16[((((size_t)m * 4 + t) * 2 + 1) * 64 + l) * 4 + j] = lo;
-                }
             }
     }
     HIP_TRY(upload(&p->pa_image, pa.data(), pa.size()));
     HIP_TRY(upload(&p->row_const, rc.data(), rc.size()));
     HIP_TRY(upload(&p->nlw, nlw.data(), nlw.size()));
-    HIP_TRY(upload(&p->mu_core, muc.data(), muc.size()));
     HIP_TRY(hipMalloc((void**)&p->frag32, f32.size() * sizeof(k2b::k2b_half)));
     HIP_TRY(hipMemcpy(p->frag32, f32.data(), f32.size() * sizeof(k2b::k2b_half), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&p->frag16, f16.size() * sizeof(k2b::k2b_half)));
-    HIP_TRY(hipMemcpy(p->frag16, f16.data(), f16.size() * sizeof(k2b::k2b_half), hipMemcpyHostToDevice));
     *out = p;
     return K2B_OK;
 }
@@ -430,10 +414,9 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
 void k2b_prior_destroy(k2b_prior* p) {
     if (!p) return;
     (void)hipDeviceSynchronize();
-    float* fl[] = {p->pa_image, p->row_const, p->nlw, p->mu_core};
+    float* fl[] = {p->pa_image, p->row_const, p->nlw};
     for (float* q : fl) if (q) (void)hipFree(q);
     if (p->frag32) (void)hipFree(p->frag32);
-    if (p->frag16) (void)hipFree(p->frag16);
     delete p;
 }
 
@@ -469,7 +452,7 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     }
     for (int i = 0; i < 4; ++i) {
         const int ai = cfg->angle_prior_index[i];
-        if (ai < 0 || ai >= 61) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: angle_prior_index[%d]=%d must be in [0,61)", i, ai);
+        if (ai < 0 || ai >= 64) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: angle_prior_index[%d]=%d must be in [0,64)", i, ai);
         a.angle_index[i] = ai;
         a.angle_sign[i] = cfg->angle_prior_sign[i];
     }
@@ -505,7 +488,7 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     }
     a.num_betas = model->NB;
     a.pa_image = prior->pa_image; a.row_const = prior->row_const; a.neg_log_nllw = prior->nlw;
-    a.pa_frag32 = prior->frag32; a.pa_frag16 = prior->frag16; a.mu_core = prior->mu_core;
+    a.pa_frag32 = prior->frag32;
     for (int m = 0; m < k2b::kPriorMaxGauss; ++m) a.inv_scale[m] = prior->inv_scale[m];
     a.frames_per_wg = 0;
     a.num_gauss = prior->M;

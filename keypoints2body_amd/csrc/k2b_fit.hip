@@ -2,45 +2,41 @@
 //
 // One launch runs ALL Adam iterations of `WorldSpaceFitter.fit_frame`'s Adam branch
 // (reference keypoints2body/core/fitters/world_space.py:248-256) for a batch of independent
-// frames.  A workgroup is always 8 wavefronts and fits up to 8 frames; nothing is read from or
+// frames.  A workgroup is always 8 wavefronts and carries up to 16 frames; nothing is read from or
 // written to HBM per iteration.
 //
-// GMM prior on the matrix cores.  y_m = P_m theta - P_m mu_m for the 8 mixture components is a
-// (8 x 69 x 69) x (69 x frames) product.  Wave w of the workgroup owns component w: rows 0..63 of
-// P_w live in ITS REGISTERS for the whole launch as MFMA A fragments (4 row tiles x K = 32 + 32 + 16),
+// GMM prior on the matrix cores.  y_m = P_m (theta - mu_m) for the 8 mixture components is a
+// (8 x 69 x 69) x (69 x frames) product.  Wave w of the workgroup owns component w: the 64 x 64 core
+// of P_w lives in ITS REGISTERS for the whole launch as MFMA A fragments (4 row tiles x K = 32 + 32),
 // split into two f16 terms (hi + lo, ~22 mantissa bits, power-of-two scaled per component) so that
-// each product is three f16 MFMAs (hi.hi + hi.lo + lo.hi) with fp32 accumulation; column 69 of the
-// fragments holds -P_w mu_w against a constant 1 in theta, so the MFMA result is y_w directly.  The B
-// operand is theta of ALL frames of the workgroup (one frame per MFMA column), published by the
-// frames' row waves as f16 hi/lo strips in LDS.  Each wave reduces its component's quadratic form per
-// frame in the accumulator layout and publishes y and q through LDS; the frame's row wave takes the
-// arg-min component.  Rows 61..68 (the rim the 64-row tiles do not cover) stay on the vector ALU.
+// each product is three f16 MFMAs (hi.hi + hi.lo + lo.hi) with fp32 accumulation.  The B operand is
+// theta[0..63] of ALL frames of the workgroup (one frame per MFMA column), published by the frames'
+// row roles as f16 hi/lo strips in LDS.  Each wave reduces its component's quadratic form per frame in
+// the accumulator layout and publishes y and q through LDS.  The rim of P (rows / columns 64..68) stays
+// on the vector ALU and uses the symmetry of P: the five rim rows give y_64..68 and, through
+// theta_B^T (P_BA d_A), the rim's share of every quadratic form; the rim columns are added to y only
+// for the arg-min component.
 //
 // Lane roles of a wave
-//   "row layout"   lane l holds optimiser state for flat parameter p = l (register set A)
-//                  and p = 64 + l (set B); p runs over [global_orient 3 | body_pose 69 |
-//                  betas NB | transl 3].  The GMM rows use this layout too: lane l <-> body
-//                  pose index l-3 (set A), lanes 0..7 of set B <-> indices 61..68.
+//   "row layout"   optimiser state: register set A, lane l <-> body_pose[l] (l = 0..63, the MFMA core
+//                  rows); set B, lane l <-> body_pose[64 + l] (l < 5), global_orient (5..7), betas
+//                  (8..8+NB-1), transl (next 3).
 //   "tree layout"  lane t < 24 owns the t-th joint of the kinematic tree in DFS pre-order, so
 //                  every subtree is a contiguous lane range.  Global transforms come from a
 //                  pointer-doubling down-sweep (log2(depth) rounds of cross-lane moves instead
-//                  of one round per level); subtree force / torque sums come from windowed
-//                  sums over lane ranges (no level loop, no cancellation).  All tree traffic is
-//                  ds_bpermute cross-lane moves: the "tree in LDS" is the LDS crossbar, with no
-//                  LDS allocation.
-// The two layouts exchange values through a 96-float wave-private LDS staging strip.
+//                  of one round per level); subtree force / torque sums are differences of one
+//                  prefix scan.  All tree traffic is ds_bpermute / DPP cross-lane moves.
+// The layouts exchange values through per-frame LDS strips.
 //
-// Two execution shapes (template parameter SPLIT):
-//   unified  one wave does everything for its frame (large batches: >= 2 waves per SIMD hide latency);
-//   split    small batches (<= 4 frames per CU) leave SIMDs idle, so each frame gets TWO waves that
-//            run concurrently on different SIMDs: the "row" wave (GMM prior + Adam, owns the
-//            optimiser state) and the "tree" wave (kinematics, joint loss, analytic backward).
-//            The two parts of an iteration are independent given the parameters, so the critical
-//            path is max(GMM, tree) instead of their sum; they meet at two workgroup barriers per
-//            iteration and exchange parameters / gradients through the LDS strips.
-//
+// Three execution shapes (template parameter MODE), chosen by frames per CU:
+//   split    <= 4 frames per CU: each frame gets TWO waves on one SIMD, the "row" wave (rim of the
+//            prior, Adam, owns the optimiser state) and the "tree" wave (kinematics, joint loss,
+//            analytic backward), so the critical path of an iteration is the tree alone;
+//   unified  <= 8: one wave does both for its frame;
+//   paired   <= 16: one wave does both for TWO frames; the two trees share the wave (one per 32-lane
+//            half), which halves the tree instructions per frame.
 // Every wave of the workgroup meets at two barriers per iteration (parameters published /
-// gradients, y and q published), in both shapes.
+// gradients, y and q published), in every shape.
 //
 // Arithmetic restated (see oracle/fit_torch.py for the CPU twin and the reference lines):
 //   joints  p_j = p_par + Rg_par (J_j(beta) - J_par(beta)),  Rg_j = Rg_par R_j   (smplx chain)
@@ -61,20 +57,22 @@ constexpr int D = kPriorDim;            // 69
 constexpr int MAXW = kFitMaxWaves;      // waves per workgroup
 constexpr int MAXS = 16;                // frame slots per workgroup (= MFMA columns)
 constexpr int MG = kPriorMaxGauss;      // 8
-constexpr int PB_FLOATS = MG * 9 * 64;            // rim rows 61..68: [m][9][64]
-static_assert(PB_FLOATS == kPriorImageFloats, "host image size");
-// per-frame-slot LDS block (floats): parameters (row wave -> tree / component waves), gradients
-// (tree wave -> row wave), then theta as f16 hi[80] | lo[80] (the MFMA B operand; index 69 = 1, 70..79 = 0)
-constexpr int XS = 96;                  // strip: go@0, body@4, betas@76, transl@92
+constexpr int NC = 64;                  // core rows / columns of a component handled by the matrix cores
+constexpr int NR = D - NC;              // 5 rim rows / columns
+// LDS (floats): rim rows of P as [10][64 lanes][4] (lane 8m + s: columns 8s..8s+7 of rows 64..68 of
+// component m), then mu | c = P mu of the core rows [m][2][64], then the per-frame-slot blocks:
+// parameters (row role -> tree / component roles), gradients (tree -> row), theta[0..63] as f16 hi | lo.
+constexpr int RIM_FLOATS = 2 * NR * 64 * 4;
+constexpr int CMU_FLOATS = MG * 2 * NC;
+static_assert(RIM_FLOATS + CMU_FLOATS == kPriorImageFloats, "host image size");
+constexpr int XS = 96;                  // strip: go@0, body@4, betas@76, transl@92, joint loss@95
 constexpr int XS_BODY = 4, XS_BETA = 76, XS_TRANSL = 92;
-constexpr int KH = 80;                  // padded K of the component product
-constexpr int SLOT = 2 * XS + KH;       // 272 floats
-constexpr int YX_STRIDE = MG * 64 + 4;  // y exchange: [slot][m][64] (+4: b128 stores of the 16 frame columns hit distinct banks)
-constexpr int LDS_FLOATS = PB_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE;
+constexpr int SLOT = 2 * XS + NC;       // 256 floats
+constexpr int YX_STRIDE = MG * NC + 4;  // y exchange: [slot][m][64] (+4: b128 stores of the 16 frame columns hit distinct banks)
+constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE;
 static_assert(LDS_FLOATS * 4 <= 163840, "LDS budget");
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // Inclusive prefix sum inside each 32-lane half with DPP (no LDS traffic): Hillis-Steele inside each
@@ -146,6 +144,15 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
     v += lane_xor4(v);
     v += lane_xor2(v);
     v += lane_xor1(v);
+    return v;
+}
+
+// sum over the 8 lanes {l ^ 1, l ^ 2, l ^ 4 ...} of a group of eight: quad_perm twice, then the
+// half-row mirror (lane i <-> 7 - i), which after the quad steps delivers the other quad's total
+__device__ __forceinline__ float group8_sum(float v) {
+    v += lane_xor1(v);
+    v += lane_xor2(v);
+    v += dpp<0x141>(v);   // row_half_mirror
     return v;
 }
 
@@ -249,11 +256,11 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const int M = a.num_gauss;
     const int F = a.frames_per_wg;           // frame slots of this workgroup (split <= 4, unified <= 8, paired <= 16)
 
-    // ---- 0. rim rows of the precisions -> LDS (shared by every wave of the workgroup) ----------
+    // ---- 0. rim of the precisions, mu and c of the core rows -> LDS (shared by the workgroup) ----------
     {
         const float4* src = reinterpret_cast<const float4*>(a.pa_image);
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = tid; i < PB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = tid; i < (RIM_FLOATS + CMU_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
     }
 
     // frame slots and roles of this wave
@@ -275,64 +282,69 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         f[h] = f_raw < a.num_frames ? f_raw : a.num_frames - 1;
     }
 
-    float* slots = lds + PB_FLOATS;
+    const float4* rim4 = reinterpret_cast<const float4*>(lds);          // [10][64]
+    const float* cmu = lds + RIM_FLOATS;                                // [m][mu | c][64]
+    float* slots = lds + RIM_FLOATS + CMU_FLOATS;
     float* qx = slots + MAXS * SLOT;                           // [slot][m]   core part of d^T P_m d
-    float* yx = qx + MAXS * MG;                                // [slot][m][64] (stride YX_STRIDE)  y_m rows 0..63
-    const float* pbl = lds;                                    // [m][9][64]
+    float* yx = qx + MAXS * MG;                                // [slot][m][64] (stride YX_STRIDE)  core part of y_m, rows 0..63
 
     const int NB = a.num_betas;
     const int nparamB = 8 + NB + 3;            // lanes of set B that hold a parameter
 
-    // ---- component role: rows 0..63 of P_wave as MFMA A fragments, resident in registers ----------
+    // ---- component role: the 64 x 64 core of P_wave as MFMA A fragments, resident in registers ----------
     // accumulator layout of v_mfma_f32_16x16x32_f16: lane (n = l & 15, g = l >> 4), register i of tile t
     // <-> row 16 t + 4 g + i of the component, column n = frame slot n.
     const int cn = lane & 15, cg = lane >> 4;
     const int cslot = cn < F ? cn : F - 1;                     // columns beyond the workgroup's frames repeat the last slot
     half8 pa_h[4][2], pa_l[4][2];
-    half4 pa_h16[4], pa_l16[4];
-    float mu_d[4][4];
     {
-        const half8* f32i = reinterpret_cast<const half8*>(a.pa_frag32) + (size_t)wave * 4 * 4 * 64;
-        const half4* f16i = reinterpret_cast<const half4*>(a.pa_frag16) + (size_t)wave * 4 * 2 * 64;
+        const half8* fi = reinterpret_cast<const half8*>(a.pa_frag32) + (size_t)wave * 4 * 4 * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            pa_h[t][0] = f32i[(t * 4 + 0) * 64 + lane];
-            pa_h[t][1] = f32i[(t * 4 + 1) * 64 + lane];
-            pa_l[t][0] = f32i[(t * 4 + 2) * 64 + lane];
-            pa_l[t][1] = f32i[(t * 4 + 3) * 64 + lane];
-            pa_h16[t] = f16i[(t * 2 + 0) * 64 + lane];
-            pa_l16[t] = f16i[(t * 2 + 1) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mu_d[t][i] = a.mu_core[wave * 64 + 16 * t + 4 * cg + i];
+            pa_h[t][0] = fi[(t * 4 + 0) * 64 + lane];
+            pa_h[t][1] = fi[(t * 4 + 1) * 64 + lane];
+            pa_l[t][0] = fi[(t * 4 + 2) * 64 + lane];
+            pa_l[t][1] = fi[(t * 4 + 3) * 64 + lane];
         }
     }
     const float inv_scale = a.inv_scale[wave];
     const float* cxs = slots + cslot * SLOT;                   // slot this lane's MFMA column reads
     const _Float16* cth_hi = reinterpret_cast<const _Float16*>(cxs + 2 * XS);
-    const _Float16* cth_lo = cth_hi + KH;
+    const _Float16* cth_lo = cth_hi + NC;
+    const float* cmu_w = cmu + wave * 2 * NC + 4 * cg;         // + 16 t: mu of this lane's rows; + NC: c
 
     // ---- 1. per-lane constants ----------------------------------------------------------
-    // row layout: staging offsets of this lane's two parameters
-    const int offA = lane < 3 ? lane : XS_BODY + (lane - 3);
-    const int offB = lane < 8 ? XS_BODY + 61 + lane : (lane < 8 + NB ? XS_BETA + (lane - 8) : XS_TRANSL + (lane - 8 - NB));
+    // row layout: which parameter the two register sets of this lane hold, and where it sits in the strips
     const bool actB = lane < nparamB;
-    const bool bodyA = lane >= 3, bodyB = lane < 8;
+    const bool bodyB = lane < NR, goB = lane >= NR && lane < 8;
     const bool betaB = lane >= 8 && lane < 8 + NB;
-    const bool translB = actB && !bodyB && !betaB;
+    const bool translB = actB && !bodyB && !goB && !betaB;
+    const int offA = XS_BODY + lane;
+    const int offB = bodyB ? XS_BODY + NC + lane : (goB ? lane - NR : (betaB ? XS_BETA + (lane - 8) : XS_TRANSL + (lane - 8 - NB)));
+    // flat parameter index in [global_orient 3 | body_pose 69 | betas NB | transl 3]
+    const int pA = 3 + lane;
+    const int pB = bodyB ? 3 + NC + lane : (goB ? lane - NR : (betaB ? 3 + D + (lane - 8) : 3 + D + NB + (lane - 8 - NB)));
     // optimiser membership of this lane's parameters (k2b_fit_config.optimize_mask)
-    const bool optA = (a.opt_mask >> (lane < 3 ? 0 : 1)) & 1;
-    const bool optB = actB && ((a.opt_mask >> (bodyB ? 1 : (betaB ? 2 : 3))) & 1);
+    const bool optA = (a.opt_mask >> 1) & 1;
+    const bool optB = actB && ((a.opt_mask >> (bodyB ? 1 : (goB ? 0 : (betaB ? 2 : 3)))) & 1);
 
-    // rim rows after the butterfly: lane (r = l&7, s = l>>3) owns row 61+r of component s
-    const float muB = a.row_const[lane];
-    const float cB = a.row_const[64 + lane];
-    const int rB = lane & 7, sB = lane >> 3;
+    // rim of the prior: lane (gm = l >> 3, gs = l & 7) works on component gm, columns 8 gs .. 8 gs + 7;
+    // lanes gs < 5 finish rim row 64 + gs of that component
+    const int gm = lane >> 3, gs = lane & 7;
+    float pbb[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) pbb[k] = a.row_const[k * 64 + lane];     // P_gm[64 + gs][64 + k]
+    const float cB = a.row_const[5 * 64 + lane];    // (P mu)[64 + gs]
+    const float kB = a.row_const[6 * 64 + lane];    // (P_BA mu_A)[gs]
+    const float muB = a.row_const[7 * 64 + lane];   // mu[64 + gs]
+    // float4 index of P_m[64 + c][lane] (= P_m[lane][64 + c]) in the rim image, without the m and c terms
+    const int rimcol = (((lane >> 2) & 1) * 64 + (lane >> 3)) * 4 + (lane & 3);
 
     // angle prior: sign (0 = not a prior index) for the set-A parameter of this lane
     float angA = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (lane == 3 + a.angle_index[i]) angA = a.angle_sign[i];
+        if (lane == a.angle_index[i]) angA = a.angle_sign[i];
 
     // tree layout constants (host tables, DFS pre-order; paired: one tree per 32-lane half)
     const int hb = PAIR ? lane >> 5 : 0;         // which of the wave's frames this lane's tree belongs to
@@ -382,21 +394,21 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     }
 
     // ---- 2. parameters and optimiser state (row layout) -----------------------------------
-    auto load_param = [&](int fr, int p, const float* go, const float* bp, const float* be, const float* tr) -> float {
-        if (p < 3) return go[(size_t)fr * 3 + p];
-        if (p < 3 + D) return bp[(size_t)fr * D + (p - 3)];
-        if (p < 3 + D + NB) return be[(size_t)fr * NB + (p - 3 - D)];
-        return tr[(size_t)fr * 3 + (p - 3 - D - NB)];
+    auto param_ptr = [&](int fr, int p, const float* go, const float* bp, const float* be, const float* tr) -> const float* {
+        if (p < 3) return go + (size_t)fr * 3 + p;
+        if (p < 3 + D) return bp + (size_t)fr * D + (p - 3);
+        if (p < 3 + D + NB) return be + (size_t)fr * NB + (p - 3 - D);
+        return tr + (size_t)fr * 3 + (p - 3 - D - NB);
     };
     const float* prsrc = a.preserve ? a.preserve : a.bp_in;
     float x0[FW], x1[FW], pr0[FW], pr1[FW], tp1[FW];
     float m0[FW], v0[FW], m1[FW], v1[FW], g0[FW], g1[FW], loss_total[FW];
 #pragma unroll
     for (int h = 0; h < FW; ++h) {
-        x0[h] = load_param(f[h], lane, a.go_in, a.bp_in, a.be_in, a.tr_in);
-        x1[h] = actB ? load_param(f[h], 64 + lane, a.go_in, a.bp_in, a.be_in, a.tr_in) : 0.f;
-        pr0[h] = bodyA ? prsrc[(size_t)f[h] * D + (lane - 3)] : 0.f;
-        pr1[h] = bodyB ? prsrc[(size_t)f[h] * D + 61 + lane] : 0.f;
+        x0[h] = *param_ptr(f[h], pA, a.go_in, a.bp_in, a.be_in, a.tr_in);
+        x1[h] = actB ? *param_ptr(f[h], pB, a.go_in, a.bp_in, a.be_in, a.tr_in) : 0.f;
+        pr0[h] = prsrc[(size_t)f[h] * D + lane];
+        pr1[h] = bodyB ? prsrc[(size_t)f[h] * D + NC + lane] : 0.f;
         tp1[h] = translB ? a.tr_prior[(size_t)f[h] * 3 + (lane - 8 - NB)] : 0.f;   // centre of the transl prior
         m0[h] = v0[h] = m1[h] = v1[h] = g0[h] = g1[h] = loss_total[h] = 0.f;
     }
@@ -410,108 +422,81 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const float om_b1 = a.one_minus_beta1;       // lerp weight float(1 - beta1), formed in double on host
     const float om_b2 = a.one_minus_beta2;       // float(1 - beta2) computed in double on host
 
-    // constant tail of the MFMA B operand: index 69 multiplies the -P mu column, 70..79 are padding
-    if (do_row && lane < KH - D) {
-#pragma unroll
-        for (int h = 0; h < FW; ++h) {
-            _Float16* th_hi = reinterpret_cast<_Float16*>(slots + (slot0 + h) * SLOT + 2 * XS);
-            th_hi[D + lane] = lane == 0 ? (_Float16)1.0f : (_Float16)0.0f;
-            th_hi[KH + D + lane] = (_Float16)0.0f;
-        }
-    }
     const bool use_gmm = wpp2 != 0.f;   // a zero pose-prior weight (camera stage 1) skips the mixture entirely
 
     for (int it = 0; it < a.num_iters; ++it) {
         const bool last = it == a.num_iters - 1;
-        // ---- a. parameters -> staging strip (fp32 for the tree and the quadratic forms, f16 hi | lo for the MFMA) ----
+        // ---- a. parameters -> staging strip (fp32 for the tree, the rim and the quadratic forms; f16 hi | lo for the MFMA) ----
         if (do_row) {
 #pragma unroll
             for (int h = 0; h < FW; ++h) {
                 float* xs = slots + (slot0 + h) * SLOT;
-                _Float16* th_hi = reinterpret_cast<_Float16*>(xs + 2 * XS);
-                _Float16* th_lo = th_hi + KH;
                 xs[offA] = x0[h];
                 if (actB) xs[offB] = x1[h];
                 if (use_gmm) {
-                    if (bodyA) {
-                        const _Float16 hh = (_Float16)x0[h];
-                        th_hi[lane - 3] = hh;
-                        th_lo[lane - 3] = (_Float16)(x0[h] - (float)hh);
-                    }
-                    if (bodyB) {
-                        const _Float16 hh = (_Float16)x1[h];
-                        th_hi[61 + lane] = hh;
-                        th_lo[61 + lane] = (_Float16)(x1[h] - (float)hh);
-                    }
+                    _Float16* th_hi = reinterpret_cast<_Float16*>(xs + 2 * XS);
+                    const _Float16 hh = (_Float16)x0[h];
+                    th_hi[lane] = hh;
+                    th_hi[NC + lane] = (_Float16)(x0[h] - (float)hh);
                 }
             }
         }
         __syncthreads();
 
-        // ---- c. GMM prior, rows 0..63 of component `wave` for every frame slot: three f16 MFMA products ----
+        // ---- c. GMM prior, 64 x 64 core of component `wave` for every frame slot: three f16 MFMA products ----
         // (small terms first; the results are consumed after the tree part, so the matrix pipe runs under it)
         floatx4 yacc[4];
         if (use_gmm) {
             const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
             const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
-            const half4 bh2 = *reinterpret_cast<const half4*>(cth_hi + 64 + 4 * cg);
             const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
             const half8 bl1 = *reinterpret_cast<const half8*>(cth_lo + 32 + 8 * cg);
-            const half4 bl2 = *reinterpret_cast<const half4*>(cth_lo + 64 + 4 * cg);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_l[t][0], bh0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_l[t][1], bh1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(pa_l16[t], bh2, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][0], bl0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][1], bl1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(pa_h16[t], bl2, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][0], bh0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][1], bh1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(pa_h16[t], bh2, acc, 0, 0, 0);
                 yacc[t] = acc;
             }
-            // keep the B fragments live past the last MFMA: the register allocator otherwise may place an
-            // MFMA destination on its own B operand (seen under pressure), which the 16x16x16 form miscomputes
-            asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bh2), "v"(bl0), "v"(bl1), "v"(bl2));
+            // keep the B fragments live past the last MFMA so that no MFMA destination is allocated on
+            // top of its own B operand
+            asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
         }
 
-        // rim rows 61..68 on the vector ALU: lane (r, s) sums columns 9s..9s+8 of row 61+r for every
-        // component (one component's reads ahead of the FMAs)
-        float yB[FW], zB[FW];
+        // ---- rim rows 64..68 on the vector ALU (row role) --------------------------------------------
+        // lane (gm, gs): w_c = sum over its 8 columns of P_gm[64 + c][col] theta[col] (columns 0..63), summed
+        // over the 8 lanes of the group; lane gs < 5 then finishes row 64 + gs:
+        //   y_B = w + P_BB theta_B - c_B
+        //   rim share of d^T P d = theta_B (P_BA d_A) + d_B y_B,   P_BA d_A = w - P_BA mu_A
+        float yB[FW], qrim[FW];
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
-            yB[h] = 0.f; zB[h] = 0.f;
+            yB[h] = 0.f; qrim[h] = 0.f;
             if (do_row && use_gmm) {
                 const float* xs = slots + (slot0 + h) * SLOT;
-                float pb[MG];
-                float tb[9], pv[2][9];
+                const float4 ta = *reinterpret_cast<const float4*>(xs + XS_BODY + 8 * gs);
+                const float4 tb = *reinterpret_cast<const float4*>(xs + XS_BODY + 8 * gs + 4);
+                const float4 t64 = *reinterpret_cast<const float4*>(xs + XS_BODY + NC);      // theta_B[0..3]
+                const float t68 = xs[XS_BODY + NC + 4];
+                float w[NR];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    const int col = 9 * sB + c;
-                    tb[c] = xs[XS_BODY + (col < D ? col : 0)];
+                for (int c = 0; c < NR; ++c) {
+                    const float4 pa = rim4[(2 * c) * 64 + lane], pb = rim4[(2 * c + 1) * 64 + lane];
+                    w[c] = pa.x * ta.x + pa.y * ta.y + pa.z * ta.z + pa.w * ta.w + pb.x * tb.x + pb.y * tb.y + pb.z * tb.z + pb.w * tb.w;
                 }
 #pragma unroll
-                for (int c = 0; c < 9; ++c) pv[0][c] = pbl[(0 * 9 + c) * 64 + lane];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < MG; ++m) {
-                    const int cur = m & 1, nxt = cur ^ 1;
-                    if (m + 1 < MG) {
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) pv[nxt][c] = pbl[((m + 1) * 9 + c) * 64 + lane];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) sacc += pv[cur][c] * tb[c];   // image is zero for columns >= 69
-                    pb[m] = sacc;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                yB[h] = butterfly8(pb, lane) - cB;                  // component sB, row 61+rB
-                const float xB = xs[XS_BODY + 61 + rB];
-                zB[h] = (xB - muB) * yB[h];
+                for (int c = 0; c < NR; ++c) w[c] = group8_sum(w[c]);
+                const float wm = gs == 0 ? w[0] : (gs == 1 ? w[1] : (gs == 2 ? w[2] : (gs == 3 ? w[3] : w[4])));
+                const float tB = gs == 0 ? t64.x : (gs == 1 ? t64.y : (gs == 2 ? t64.z : (gs == 3 ? t64.w : t68)));
+                const float vB = pbb[0] * t64.x + pbb[1] * t64.y + pbb[2] * t64.z + pbb[3] * t64.w + pbb[4] * t68;
+                const float y = wm + vB - cB;
+                const float term = tB * (wm - kB) + (tB - muB) * y;
+                yB[h] = gs < NR ? y : 0.f;
+                qrim[h] = group8_sum(gs < NR ? term : 0.f);      // every lane of group gm: rim share of component gm
             }
         }
 
@@ -643,22 +628,21 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         if (tl == 0) { gs_t[XS_TRANSL] = aj.x; gs_t[XS_TRANSL + 1] = aj.y; gs_t[XS_TRANSL + 2] = aj.z; gs_t[XS - 1] = jloss; }
         }  // do_tree
 
-        // ---- component role: y = D / scale, core part of the quadratic form per frame, publish both ----
+        // ---- component role: y = D / scale - c, core part of the quadratic form per frame, publish both ----
         if (use_gmm) {
             float qp = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float4 th4 = *reinterpret_cast<const float4*>(cxs + XS_BODY + 16 * t + 4 * cg);
-                const float thv[4] = {th4.x, th4.y, th4.z, th4.w};
-                float y[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    y[i] = yacc[t][i] * inv_scale;
-                    float d = thv[i] - mu_d[t][i];
-                    if (t == 3 && i >= 1) d = cg == 3 ? 0.f : d;   // rows 61..63 belong to the rim path
-                    qp += d * y[i];
-                }
-                if (cn < F) *reinterpret_cast<float4*>(yx + cn * YX_STRIDE + wave * 64 + 16 * t + 4 * cg) = make_float4(y[0], y[1], y[2], y[3]);
+                const float4 mu4 = *reinterpret_cast<const float4*>(cmu_w + 16 * t);
+                const float4 c4 = *reinterpret_cast<const float4*>(cmu_w + NC + 16 * t);
+                float4 y;
+                y.x = yacc[t][0] * inv_scale - c4.x;
+                y.y = yacc[t][1] * inv_scale - c4.y;
+                y.z = yacc[t][2] * inv_scale - c4.z;
+                y.w = yacc[t][3] * inv_scale - c4.w;
+                qp += (th4.x - mu4.x) * y.x + (th4.y - mu4.y) * y.y + (th4.z - mu4.z) * y.z + (th4.w - mu4.w) * y.w;
+                if (cn < F) *reinterpret_cast<float4*>(yx + cn * YX_STRIDE + wave * NC + 16 * t + 4 * cg) = y;
             }
             qp = pair_sum32(qp);
             qp = pair_sum16(qp);                             // summed over the four row groups g
@@ -670,16 +654,13 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
         const int slot = slot0 + h;
-        const float* gs = slots + slot * SLOT + XS;
+        const float* xs = slots + slot * SLOT;
+        const float* gs_r = xs + XS;
         // ---- arg-min component of this frame, its y in row layout --------------------------------------
         float yA = 0.f, yBs = 0.f, best = 0.f;
         if (use_gmm) {
-            float q = zB[h];
-            q += lane_xor4(q);
-            q += lane_xor2(q);
-            q += lane_xor1(q);                                   // lanes 8m..8m+7: rim part of d^T P d of component m
-            q += qx[slot * MG + sB];
-            const float val = 0.5f * q + a.neg_log_nllw[sB < M ? sB : 0];
+            const float q = qrim[h] + qx[slot * MG + gm];        // lanes 8m..8m+7: d^T P d of component m
+            const float val = 0.5f * q + a.neg_log_nllw[gm < M ? gm : 0];
             best = read_lane(val, 0);
             int mstar = 0;
 #pragma unroll
@@ -687,15 +668,20 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 const float vm = read_lane(val, 8 * m);
                 if (m < M && vm < best) { best = vm; mstar = m; }
             }
-            yA = bodyA ? yx[slot * YX_STRIDE + mstar * 64 + (lane - 3)] : 0.f;
-            yBs = bperm((rB + 8 * mstar) * 4, yB[h]);   // row 61+lane for lanes < 8
+            // rows 0..63: core part from the component wave + the rim columns, P[l][64 + c] = P[64 + c][l]
+            yA = yx[slot * YX_STRIDE + mstar * NC + lane];
+            const float4 t64 = *reinterpret_cast<const float4*>(xs + XS_BODY + NC);
+            const float t68 = xs[XS_BODY + NC + 4];
+            const float* rimf = lds + mstar * 32 + rimcol;
+            yA += rimf[0 * 512] * t64.x + rimf[1 * 512] * t64.y + rimf[2 * 512] * t64.z + rimf[3 * 512] * t64.w + rimf[4 * 512] * t68;
+            yBs = bperm((8 * mstar + (lane < NR ? lane : 0)) * 4, yB[h]);   // rows 64 + lane for lanes < 5
         }
         // ---- row layout: gradients of the joint term, then the priors ---------------------------------
-        g0[h] = gs[offA];
-        g1[h] = actB ? gs[offB] : 0.f;
-        const float jloss = gs[XS - 1];
+        g0[h] = gs_r[offA];
+        g1[h] = actB ? gs_r[offB] : 0.f;
+        const float jloss = gs_r[XS - 1];
         float part = 0.f;                  // per-lane partial of the prior losses
-        if (bodyA) {
+        {
             g0[h] += wpp2 * yA + 2.f * wpr2 * (x0[h] - pr0[h]);
             if (angA != 0.f) {
                 const float e = __expf(x0[h] * angA);
@@ -739,23 +725,23 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     if (!do_row) return;
 
     // ---- 4. results -----------------------------------------------------------------------------------
+    auto out_ptr = [&](int fr, int p) -> float* {
+        if (p < 3) return a.go_out + (size_t)fr * 3 + p;
+        if (p < 3 + D) return a.bp_out + (size_t)fr * D + (p - 3);
+        if (p < 3 + D + NB) return a.be_out + (size_t)fr * NB + (p - 3 - D);
+        return a.tr_out + (size_t)fr * 3 + (p - 3 - D - NB);
+    };
 #pragma unroll
     for (int h = 0; h < FW; ++h) {
         if (!f_valid[h]) continue;
         const int fr = f[h];
-        auto store_param = [&](int p, float v) {
-            if (p < 3) a.go_out[(size_t)fr * 3 + p] = v;
-            else if (p < 3 + D) a.bp_out[(size_t)fr * D + (p - 3)] = v;
-            else if (p < 3 + D + NB) a.be_out[(size_t)fr * NB + (p - 3 - D)] = v;
-            else a.tr_out[(size_t)fr * 3 + (p - 3 - D - NB)] = v;
-        };
-        store_param(lane, x0[h]);
-        if (actB) store_param(64 + lane, x1[h]);
+        *out_ptr(fr, pA) = x0[h];
+        if (actB) *out_ptr(fr, pB) = x1[h];
         if (lane == 0 && a.loss_out) a.loss_out[fr] = loss_total[h];
         if (a.grad_out) {
             const int P = 3 + D + NB + 3;
-            a.grad_out[(size_t)fr * P + lane] = optA ? g0[h] : 0.f;
-            if (actB) a.grad_out[(size_t)fr * P + 64 + lane] = optB ? g1[h] : 0.f;
+            a.grad_out[(size_t)fr * P + pA] = optA ? g0[h] : 0.f;
+            if (actB) a.grad_out[(size_t)fr * P + pB] = optB ? g1[h] : 0.f;
         }
     }
 }

@@ -15,13 +15,13 @@ constexpr int kFitMaxWaves = 8;     // frames (waves) per workgroup
 constexpr int kMaxJoints = 64;
 constexpr int kMaxRounds = 4;       // pointer-doubling rounds: tree depth < 2^4
 constexpr int kLaneTabStride = 8;   // ints per lane: joint, parent lane, anc[kMaxRounds], subtree size, depth
-// LDS image of the prior's rim rows 61..68: [8][9][64]
-constexpr int kPriorImageFloats = kPriorMaxGauss * 9 * 64;
-// rows 0..63 of every component as MFMA A fragments (f16 hi / lo, see k2b_api.hip):
-//   frag32 [m][tile 4][ks0 hi, ks1 hi, ks0 lo, ks1 lo][64 lanes][8 halfs]   (K = 0..63)
-//   frag16 [m][tile 4][hi, lo][64 lanes][4 halfs]                          (K = 64..79: cols 64..68, -P mu, 0)
+// LDS image of the prior: rim rows 64..68 over columns 0..63 as [10][64 lanes][4] (lane 8m + s holds
+// columns 8s..8s+7 of the five rows of component m: float4 2c and 2c+1 for row 64+c), then mu | c = P mu
+// of rows 0..63 as [m][2][64]
+constexpr int kPriorImageFloats = 2 * 5 * 64 * 4 + kPriorMaxGauss * 2 * 64;
+// the 64 x 64 core of every component as MFMA A fragments (f16 hi / lo, see k2b_api.hip):
+//   [m][tile 4][ks0 hi, ks1 hi, ks0 lo, ks1 lo][64 lanes][8 halfs]
 constexpr int kPriorFrag32Halfs = kPriorMaxGauss * 4 * 4 * 64 * 8;
-constexpr int kPriorFrag16Halfs = kPriorMaxGauss * 4 * 2 * 64 * 4;
 
 // Kernel arguments of the fused fit (passed by value).
 struct FitArgs {
@@ -33,11 +33,9 @@ struct FitArgs {
     int num_rounds;             // pointer-doubling rounds needed by the targeted joints of this call
     int num_betas;
     // prior (device)
-    const float* pa_image;      // LDS image of the rim rows, kPriorImageFloats floats (see k2b_api.hip)
+    const float* pa_image;      // LDS image, kPriorImageFloats floats (see k2b_api.hip)
     const void* pa_frag32;      // kPriorFrag32Halfs f16
-    const void* pa_frag16;      // kPriorFrag16Halfs f16
-    const float* mu_core;       // [8][64] means of rows 0..63
-    const float* row_const;     // muB[64], cB[64]  (rim rows after the butterfly)
+    const float* row_const;     // [8][64] per-lane rim constants: P_BB row (5), (P mu)_B, (P_BA mu_A), mu_B
     const float* neg_log_nllw;  // [8]
     float inv_scale[kPriorMaxGauss];  // 1 / (power-of-two scale of component m's fragments)
     int num_gauss;
