@@ -110,31 +110,4 @@ __device__ __forceinline__ Rodrigues rodrigues_fwd(Vec3 th) {
     return o;
 }
 
-// Reverse mode of rodrigues_fwd: G = dL/dR (row-major) -> dL/dtheta, following the same
-// elementary operations autograd differentiates (norm, divide, sin, cos, K, K K).
-__device__ __forceinline__ Vec3 rodrigues_bwd(const Rodrigues& f, Vec3 th, const Mat3& G) {
-    const float ux = f.u.x, uy = f.u.y, uz = f.u.z;
-    const float omc = 1.0f - f.c;
-    // <G, K>
-    const float g_s = ux * (G.m[7] - G.m[5]) + uy * (G.m[2] - G.m[6]) + uz * (G.m[3] - G.m[1]);
-    // <G, K K>
-    const float xx = ux * ux, yy = uy * uy, zz = uz * uz, xy = ux * uy, xz = ux * uz, yz = uy * uz;
-    const float g_omc = G.m[0] * (-(yy + zz)) + G.m[4] * (-(xx + zz)) + G.m[8] * (-(xx + yy)) +
-                        (G.m[1] + G.m[3]) * xy + (G.m[2] + G.m[6]) * xz + (G.m[5] + G.m[7]) * yz;
-    // H = dL/dK = s G + omc (G K^T + K^T G)
-    Mat3 K;
-    K.m[0] = 0.f; K.m[1] = -uz; K.m[2] = uy;
-    K.m[3] = uz;  K.m[4] = 0.f; K.m[5] = -ux;
-    K.m[6] = -uy; K.m[7] = ux;  K.m[8] = 0.f;
-    const Mat3 GK = mul(G, K), KG = mul(K, G);  // K^T = -K
-    Mat3 H;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) H.m[i] = f.s * G.m[i] - omc * (GK.m[i] + KG.m[i]);
-    const Vec3 g_u = {H.m[7] - H.m[5], H.m[2] - H.m[6], H.m[3] - H.m[1]};
-    const float ia = f.inv_angle;
-    const float g_a = f.c * g_s + f.s * g_omc - (g_u.x * th.x + g_u.y * th.y + g_u.z * th.z) * (ia * ia);
-    return {(g_u.x + g_a * (th.x + 1e-8f)) * ia, (g_u.y + g_a * (th.y + 1e-8f)) * ia,
-            (g_u.z + g_a * (th.z + 1e-8f)) * ia};
-}
-
 }  // namespace k2b

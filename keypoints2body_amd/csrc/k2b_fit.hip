@@ -296,22 +296,9 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // <-> row 16 t + 4 g + i of the component, column n = frame slot n.
     const int cn = lane & 15, cg = lane >> 4;
     const int cslot = cn < F ? cn : F - 1;                     // columns beyond the workgroup's frames repeat the last slot
-    half8 pa_h[4][2], pa_l[4][2];
-    {
-        const half8* fi = reinterpret_cast<const half8*>(a.pa_frag32) + (size_t)wave * 4 * 4 * 64;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            pa_h[t][0] = fi[(t * 4 + 0) * 64 + lane];
-            pa_h[t][1] = fi[(t * 4 + 1) * 64 + lane];
-            pa_l[t][0] = fi[(t * 4 + 2) * 64 + lane];
-            pa_l[t][1] = fi[(t * 4 + 3) * 64 + lane];
-        }
-    }
-    const float inv_scale = a.inv_scale[wave];
     const float* cxs = slots + cslot * SLOT;                   // slot this lane's MFMA column reads
     const _Float16* cth_hi = reinterpret_cast<const _Float16*>(cxs + 2 * XS);
     const _Float16* cth_lo = cth_hi + NC;
-    const float* cmu_w = cmu + wave * 2 * NC + 4 * cg;         // + 16 t: mu of this lane's rows; + NC: c
 
     // ---- 1. per-lane constants ----------------------------------------------------------
     // row layout: which parameter the two register sets of this lane hold, and where it sits in the strips
@@ -424,10 +411,9 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 
     const bool use_gmm = wpp2 != 0.f;   // a zero pose-prior weight (camera stage 1) skips the mixture entirely
 
-    for (int it = 0; it < a.num_iters; ++it) {
-        const bool last = it == a.num_iters - 1;
-        // ---- a. parameters -> staging strip (fp32 for the tree, the rim and the quadratic forms; f16 hi | lo for the MFMA) ----
-        if (do_row) {
+    // ---- a. parameters -> staging strips (fp32 for the tree, the rim and the quadratic forms; f16 hi | lo for the MFMA) ----
+    auto publish = [&]() {
+        {
 #pragma unroll
             for (int h = 0; h < FW; ++h) {
                 float* xs = slots + (slot0 + h) * SLOT;
@@ -441,42 +427,43 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 }
             }
         }
-        __syncthreads();
+    };
 
-        // ---- c. GMM prior, 64 x 64 core of component `wave` for every frame slot: three f16 MFMA products ----
-        // (small terms first; the results are consumed after the tree part, so the matrix pipe runs under it)
-        floatx4 yacc[4];
-        if (use_gmm) {
-            const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
-            const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
-            const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
-            const half8 bl1 = *reinterpret_cast<const half8*>(cth_lo + 32 + 8 * cg);
+    // ---- c. GMM prior, 64 x 64 core of one component for every frame slot: three f16 MFMA products ----
+    // (small terms first; the results are consumed later in the iteration, so the matrix pipe runs under
+    //  the vector work issued in between)
+    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&pl)[4][2], floatx4 (&yacc)[4]) {
+        const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
+        const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
+        const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
+        const half8 bl1 = *reinterpret_cast<const half8*>(cth_lo + 32 + 8 * cg);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_l[t][0], bh0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_l[t][1], bh1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][0], bl0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][1], bl1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][0], bh0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa_h[t][1], bh1, acc, 0, 0, 0);
-                yacc[t] = acc;
-            }
-            // keep the B fragments live past the last MFMA so that no MFMA destination is allocated on
-            // top of its own B operand
-            asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+        for (int t = 0; t < 4; ++t) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][0], bh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][1], bh1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bl0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bl1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bh1, acc, 0, 0, 0);
+            yacc[t] = acc;
         }
+        // keep the B fragments live past the last MFMA so that no MFMA destination is allocated on
+        // top of its own B operand
+        asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+    };
 
-        // ---- rim rows 64..68 on the vector ALU (row role) --------------------------------------------
-        // lane (gm, gs): w_c = sum over its 8 columns of P_gm[64 + c][col] theta[col] (columns 0..63), summed
-        // over the 8 lanes of the group; lane gs < 5 then finishes row 64 + gs:
-        //   y_B = w + P_BB theta_B - c_B
-        //   rim share of d^T P d = theta_B (P_BA d_A) + d_B y_B,   P_BA d_A = w - P_BA mu_A
-        float yB[FW], qrim[FW];
+    // ---- rim rows 64..68 on the vector ALU (row role) --------------------------------------------
+    // lane (gm, gs): w_c = sum over its 8 columns of P_gm[64 + c][col] theta[col] (columns 0..63), summed
+    // over the 8 lanes of the group; lane gs < 5 then finishes row 64 + gs:
+    //   y_B = w + P_BB theta_B - c_B
+    //   rim share of d^T P d = theta_B (P_BA d_A) + d_B y_B,   P_BA d_A = w - P_BA mu_A
+    float yB[FW], qrim[FW];
+    auto rim = [&]() {
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
             yB[h] = 0.f; qrim[h] = 0.f;
-            if (do_row && use_gmm) {
+            if (use_gmm) {
                 const float* xs = slots + (slot0 + h) * SLOT;
                 const float4 ta = *reinterpret_cast<const float4*>(xs + XS_BODY + 8 * gs);
                 const float4 tb = *reinterpret_cast<const float4*>(xs + XS_BODY + 8 * gs + 4);
@@ -500,7 +487,9 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             }
         }
 
-        if (do_tree) {
+    };
+
+    auto tree_pass = [&](bool last) {
         // ---- b/d. tree-layout reads, J(beta), Rodrigues ---------------------------------------------
         const Vec3 th = {xs_t[thoff], xs_t[thoff + 1], xs_t[thoff + 2]};
         const Vec3 tr = {xs_t[XS_TRANSL], xs_t[XS_TRANSL + 1], xs_t[XS_TRANSL + 2]};
@@ -626,31 +615,32 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         if (gk_writer && gk < NB) gs_t[XS_BETA + gk] = gbeta;
         // the root's subtree is the whole tree: its force sum is d/d transl
         if (tl == 0) { gs_t[XS_TRANSL] = aj.x; gs_t[XS_TRANSL + 1] = aj.y; gs_t[XS_TRANSL + 2] = aj.z; gs_t[XS - 1] = jloss; }
-        }  // do_tree
+    };
 
-        // ---- component role: y = D / scale - c, core part of the quadratic form per frame, publish both ----
-        if (use_gmm) {
-            float qp = 0.f;
+    // ---- component role: y = D / scale - c, core part of the quadratic form per frame, publish both ----
+    auto comp_consume = [&](const floatx4 (&yacc)[4], int comp) {
+        const float inv_scale = a.inv_scale[comp];
+        const float* cmu_c = cmu + comp * 2 * NC + 4 * cg;     // + 16 t: mu of this lane's rows; + NC: c
+        float qp = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 th4 = *reinterpret_cast<const float4*>(cxs + XS_BODY + 16 * t + 4 * cg);
-                const float4 mu4 = *reinterpret_cast<const float4*>(cmu_w + 16 * t);
-                const float4 c4 = *reinterpret_cast<const float4*>(cmu_w + NC + 16 * t);
-                float4 y;
-                y.x = yacc[t][0] * inv_scale - c4.x;
-                y.y = yacc[t][1] * inv_scale - c4.y;
-                y.z = yacc[t][2] * inv_scale - c4.z;
-                y.w = yacc[t][3] * inv_scale - c4.w;
-                qp += (th4.x - mu4.x) * y.x + (th4.y - mu4.y) * y.y + (th4.z - mu4.z) * y.z + (th4.w - mu4.w) * y.w;
-                if (cn < F) *reinterpret_cast<float4*>(yx + cn * YX_STRIDE + wave * NC + 16 * t + 4 * cg) = y;
-            }
-            qp = pair_sum32(qp);
-            qp = pair_sum16(qp);                             // summed over the four row groups g
-            if (cg == 0 && cn < F) qx[cn * MG + wave] = qp;
+        for (int t = 0; t < 4; ++t) {
+            const float4 th4 = *reinterpret_cast<const float4*>(cxs + XS_BODY + 16 * t + 4 * cg);
+            const float4 mu4 = *reinterpret_cast<const float4*>(cmu_c + 16 * t);
+            const float4 c4 = *reinterpret_cast<const float4*>(cmu_c + NC + 16 * t);
+            float4 y;
+            y.x = yacc[t][0] * inv_scale - c4.x;
+            y.y = yacc[t][1] * inv_scale - c4.y;
+            y.z = yacc[t][2] * inv_scale - c4.z;
+            y.w = yacc[t][3] * inv_scale - c4.w;
+            qp += (th4.x - mu4.x) * y.x + (th4.y - mu4.y) * y.y + (th4.z - mu4.z) * y.z + (th4.w - mu4.w) * y.w;
+            if (cn < F) *reinterpret_cast<float4*>(yx + cn * YX_STRIDE + comp * NC + 16 * t + 4 * cg) = y;
         }
-        __syncthreads();
+        qp = pair_sum32(qp);
+        qp = pair_sum16(qp);                             // summed over the four row groups g
+        if (cg == 0 && cn < F) qx[cn * MG + comp] = qp;
+    };
 
-        if (do_row) {
+    auto row_update = [&](int it, bool last) {
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
         const int slot = slot0 + h;
@@ -720,7 +710,69 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             x1[h] = x1[h] - co.x * (m1[h] * fast_rcp(denom));
         }
         }  // frames of this wave
-        }  // do_row
+    };
+
+    auto load_frags = [&](int comp, half8 (&ph)[4][2], half8 (&pl)[4][2]) {
+        const half8* fi = reinterpret_cast<const half8*>(a.pa_frag32) + (size_t)comp * 4 * 4 * 64;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ph[t][0] = fi[(t * 4 + 0) * 64 + lane];
+            ph[t][1] = fi[(t * 4 + 1) * 64 + lane];
+            pl[t][0] = fi[(t * 4 + 2) * 64 + lane];
+            pl[t][1] = fi[(t * 4 + 3) * 64 + lane];
+        }
+    };
+
+    // Two workgroup barriers per iteration in every role: [parameters published] and [gradients, y, q
+    // published].  The roles of the split shape run their own loops, so that the tree waves carry no
+    // component registers and the row waves no tree registers.
+    if (SPLIT && wave >= 4) {
+        // tree waves: kinematics, joint loss, analytic backward
+        for (int it = 0; it < a.num_iters; ++it) {
+            __syncthreads();
+            if (do_tree) tree_pass(it == a.num_iters - 1);
+            __syncthreads();
+        }
+        return;
+    }
+    if (SPLIT) {
+        // row waves: optimiser state of slot `wave`, mixture components `wave` and `wave + 4`
+        half8 pa_h[4][2], pa_l[4][2], pb_h[4][2], pb_l[4][2];
+        load_frags(wave, pa_h, pa_l);
+        load_frags(wave + 4, pb_h, pb_l);
+        for (int it = 0; it < a.num_iters; ++it) {
+            const bool last = it == a.num_iters - 1;
+            if (do_row) publish();
+            __syncthreads();
+            floatx4 ya[4], yb[4];
+            if (use_gmm) {
+                comp_issue(pa_h, pa_l, ya);
+                comp_issue(pb_h, pb_l, yb);
+            }
+            if (do_row) rim();
+            if (use_gmm) {
+                comp_consume(ya, wave);
+                comp_consume(yb, wave + 4);
+            }
+            __syncthreads();
+            if (do_row) row_update(it, last);
+        }
+    } else {
+        // unified / paired: every wave carries component `wave` and the row and tree roles of its slot(s)
+        half8 pa_h[4][2], pa_l[4][2];
+        load_frags(wave, pa_h, pa_l);
+        for (int it = 0; it < a.num_iters; ++it) {
+            const bool last = it == a.num_iters - 1;
+            if (do_row) publish();
+            __syncthreads();
+            floatx4 ya[4];
+            if (use_gmm) comp_issue(pa_h, pa_l, ya);
+            if (do_row) rim();
+            if (do_tree) tree_pass(last);
+            if (use_gmm) comp_consume(ya, wave);
+            __syncthreads();
+            if (do_row) row_update(it, last);
+        }
     }
     if (!do_row) return;
 
