@@ -67,7 +67,7 @@ constexpr int CMU_FLOATS = MG * 2 * NC;
 static_assert(RIM_FLOATS + CMU_FLOATS == kPriorImageFloats, "host image size");
 constexpr int XS = 96;                  // strip: go@0, body@4, betas@76, transl@92, joint loss@95
 constexpr int XS_BODY = 4, XS_BETA = 76, XS_TRANSL = 92;
-constexpr int SLOT = 2 * XS + NC;       // 256 floats
+constexpr int SLOT = 2 * XS + NC + 4;   // 260 floats: the +4 spreads the 16 frame columns of the MFMA-side reads over the banks
 constexpr int YX_STRIDE = MG * NC + 4;  // y exchange: [slot][m][64] (+4: b128 stores of the 16 frame columns hit distinct banks)
 constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE;
 static_assert(LDS_FLOATS * 4 <= 163840, "LDS budget");
