@@ -412,7 +412,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const bool use_gmm = wpp2 != 0.f;   // a zero pose-prior weight (camera stage 1) skips the mixture entirely
 
     // ---- a. parameters -> staging strips (fp32 for the tree, the rim and the quadratic forms; f16 hi | lo for the MFMA) ----
-    auto publish = [&]() {
+    auto publish = [&]() __attribute__((always_inline)) {
         {
 #pragma unroll
             for (int h = 0; h < FW; ++h) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // ---- c. GMM prior, 64 x 64 core of one component for every frame slot: three f16 MFMA products ----
     // (small terms first; the results are consumed later in the iteration, so the matrix pipe runs under
     //  the vector work issued in between)
-    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&pl)[4][2], floatx4 (&yacc)[4]) {
+    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&pl)[4][2], floatx4 (&yacc)[4]) __attribute__((always_inline)) {
         const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
         const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
         const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     //   y_B = w + P_BB theta_B - c_B
     //   rim share of d^T P d = theta_B (P_BA d_A) + d_B y_B,   P_BA d_A = w - P_BA mu_A
     float yB[FW], qrim[FW];
-    auto rim = [&]() {
+    auto rim = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
             yB[h] = 0.f; qrim[h] = 0.f;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 
     };
 
-    auto tree_pass = [&](bool last) {
+    auto tree_pass = [&](bool last) __attribute__((always_inline)) {
         // ---- b/d. tree-layout reads, J(beta), Rodrigues ---------------------------------------------
         const Vec3 th = {xs_t[thoff], xs_t[thoff + 1], xs_t[thoff + 2]};
         const Vec3 tr = {xs_t[XS_TRANSL], xs_t[XS_TRANSL + 1], xs_t[XS_TRANSL + 2]};
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     };
 
     // ---- component role: y = D / scale - c, core part of the quadratic form per frame, publish both ----
-    auto comp_consume = [&](const floatx4 (&yacc)[4], int comp) {
+    auto comp_consume = [&](const floatx4 (&yacc)[4], int comp) __attribute__((always_inline)) {
         const float inv_scale = a.inv_scale[comp];
         const float* cmu_c = cmu + comp * 2 * NC + 4 * cg;     // + 16 t: mu of this lane's rows; + NC: c
         float qp = 0.f;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         if (cg == 0 && cn < F) qx[cn * MG + comp] = qp;
     };
 
-    auto row_update = [&](int it, bool last) {
+    auto row_update = [&](int it, bool last) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
         const int slot = slot0 + h;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         }  // frames of this wave
     };
 
-    auto load_frags = [&](int comp, half8 (&ph)[4][2], half8 (&pl)[4][2]) {
+    auto load_frags = [&](int comp, half8 (&ph)[4][2], half8 (&pl)[4][2]) __attribute__((always_inline)) {
         const half8* fi = reinterpret_cast<const half8*>(a.pa_frag32) + (size_t)comp * 4 * 4 * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
