@@ -157,6 +157,16 @@ int k2b_lbs(const k2b_model *model, int32_t num_frames, const float *global_orie
             const float *body_pose, const float *betas, const float *transl,
             float *joints_out, float *vertices_out, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * k2b_angular_error_deg — the evaluation metric behind MPJAE.  Replaces
+ * `compute_angular_error_deg` (reference cli/eval.py:131-140, with `rotvec_to_rotmat`
+ * :88-128) for n pairs of axis-angle rotations:
+ *   pred, gt dev [n][3]; err_deg_out dev [n] = geodesic angle in degrees, clipped like
+ *   the reference (cos in [-1 + 1e-6, 1 - 1e-6]).  n == 0 is a no-op.
+ * ------------------------------------------------------------------------------- */
+int k2b_angular_error_deg(int64_t n, const float *pred_rotvec, const float *gt_rotvec,
+                          float *err_deg_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -571,4 +571,16 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     return K2B_OK;
 }
 
+int k2b_angular_error_deg(int64_t n, const float* pred_rotvec, const float* gt_rotvec, float* err_deg_out, void* stream_v) {
+    if (n < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_angular_error_deg: n=%lld must be >= 0", (long long)n);
+    if (n == 0) return K2B_OK;
+    if (!pred_rotvec || !gt_rotvec || !err_deg_out) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_angular_error_deg: NULL buffer");
+    if (n > (int64_t)0x7fffffff * 256) return fail(K2B_ERR_UNSUPPORTED, "k2b_angular_error_deg: n=%lld exceeds one launch", (long long)n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(K2B_ERR_NO_DEVICE, "k2b_angular_error_deg: no HIP device visible (this engine has no CPU path)");
+    HIP_TRY(k2b::launch_angular_error(pred_rotvec, gt_rotvec, err_deg_out, (long long)n, (hipStream_t)stream_v));
+    return K2B_OK;
+}
+
 }  // extern "C"

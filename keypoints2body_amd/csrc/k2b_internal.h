@@ -111,4 +111,7 @@ hipError_t launch_gather_joints(const float* verts, const int* ids, float* joint
 hipError_t launch_jreg_contract(const float* j_regressor, const float* rhs, float* out, int J, int V, int N,
                                 float* partial_ws, int num_splits, hipStream_t stream);
 
+// Geodesic angle (degrees) between n pairs of axis-angle rotations (evaluation metric, k2b_metrics.hip).
+hipError_t launch_angular_error(const float* pred, const float* gt, float* out, long long n, hipStream_t stream);
+
 }  // namespace k2b

@@ -26,7 +26,7 @@ K2B_ERR_NO_DEVICE = -4
 EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
     "k2b_model_joint_basis", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
-    "k2b_fit_world", "k2b_lbs",
+    "k2b_fit_world", "k2b_lbs", "k2b_angular_error_deg",
 )
 
 
@@ -95,6 +95,8 @@ def load_library():
     lib.k2b_fit_world.argtypes = [vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 14 + [vp]
     lib.k2b_lbs.restype = C.c_int
     lib.k2b_lbs.argtypes = [vp, C.c_int32] + [fp] * 6 + [vp]
+    lib.k2b_angular_error_deg.restype = C.c_int
+    lib.k2b_angular_error_deg.argtypes = [C.c_int64, fp, fp, fp, vp]
     _lib = lib
     return lib
 
@@ -290,4 +292,19 @@ def fit_world(model: NativeModel, prior: NativePrior, cfg: FitConfigC, model_joi
             C.c_void_p(out["betas"].data_ptr()), C.c_void_p(out["transl"].data_ptr()),
             C.c_void_p(out["loss"].data_ptr()),
             C.c_void_p(out["grad"].data_ptr()) if want_grad else None, stream), "k2b_fit_world")
+    return out
+
+
+def angular_error_deg(pred_rotvec: torch.Tensor, gt_rotvec: torch.Tensor) -> torch.Tensor:
+    """Geodesic angle in degrees between pairs of axis-angle rotations, (..., 3) x (..., 3) -> (...)
+    (``k2b_angular_error_deg``; launched on the current stream of the tensors' device)."""
+    dev = require_device(pred_rotvec.device if isinstance(pred_rotvec, torch.Tensor) else None)
+    if tuple(pred_rotvec.shape) != tuple(gt_rotvec.shape) or pred_rotvec.shape[-1] != 3:
+        raise ValueError(f"expected two (...,3) tensors of equal shape, got {tuple(pred_rotvec.shape)} and {tuple(gt_rotvec.shape)}")
+    n = pred_rotvec.numel() // 3
+    out = torch.empty(pred_rotvec.shape[:-1], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _check(load_library().k2b_angular_error_deg(n, _dev(pred_rotvec, "pred_rotvec", dev), _dev(gt_rotvec, "gt_rotvec", dev),
+                                                    C.c_void_p(out.data_ptr()) if n else None, stream), "k2b_angular_error_deg")
     return out
