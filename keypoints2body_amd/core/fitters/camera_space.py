@@ -1,6 +1,6 @@
 """Camera-space two-stage fitter on the HIP engine.
 
-Drop-in for the Adam branch of the reference's ``CameraSpaceFitter``
+Drop-in for the reference's ``CameraSpaceFitter``
 (reference ``keypoints2body/core/fitters/camera_space.py:44-339``).  Both stages run in the same
 fused kernel as the world fitter (``k2b_fit_world``): the camera translation takes the place of
 ``transl`` (it is added to the joints inside the loss, ``core/losses.py:46-47``), and the stages
@@ -16,6 +16,11 @@ differ only in the fit configuration:
 * result (``:300-339``): model-space joints / vertices (no translation applied), ``params.transl``
   = camera translation, ``loss`` = the loss re-evaluated at the fitted parameters with joint
   weight 600 and no preserve term (an evaluate-only launch: one iteration with step size 0).
+
+``use_lbfgs=True`` (``camera_space.py:144-182, 229-267``) keeps ``torch.optim.LBFGS`` (strong Wolfe) as the
+outer algorithm of both stages, as the reference does; every closure evaluation is one evaluate-only
+launch of the same kernel with the stage's configuration (loss and analytic gradient, no autograd
+graph).  L-BFGS couples the parameters it is given, so that mode fits one frame at a time.
 
 Like the reference (whose broadcasts only hold for one frame per call) ``fit_frame`` treats every
 frame independently; unlike it, any number of frames may be passed at once.
@@ -69,10 +74,6 @@ class CameraSpaceFitter:
                   seq_ind: int = 0, target_model_indices: Optional[torch.Tensor] = None,
                   joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = True,
                   init_cam_t: Optional[torch.Tensor] = None) -> BodyModelFitResult:
-        if self.use_lbfgs:
-            raise NotImplementedError(
-                "use_lbfgs=True: the HIP engine implements the Adam branch of CameraSpaceFitter only; "
-                "set FrameOptimizeConfig(use_lbfgs=False)")
         J = self.smpl.num_joints
         go = self._dev(init_params.global_orient, 3)
         bp = self._dev(init_params.body_pose, 3 * (J - 1))
@@ -109,20 +110,24 @@ class CameraSpaceFitter:
             p["betas"], p["transl"], transl_prior_target=cam_t0)
 
         # stage 1: [global_orient, camera_translation] on the torso joints
-        cfg = native.default_fit_config()
-        cfg.num_iters, cfg.step_size = int(self.num_iters), float(self.step_size)
-        cfg.sigma, cfg.joint_loss_weight = _SQUARED_ERROR_SIGMA, 1.0
-        cfg.pose_prior_weight = cfg.angle_prior_weight = cfg.shape_prior_weight = cfg.pose_preserve_weight = 0.0
-        cfg.optimize_mask, cfg.transl_prior_weight = 9, depth_w
-        s1 = fit(cfg, stage1_idx, stage1_tgt, None, dict(global_orient=go, body_pose=bp, betas=be, transl=cam_t0))
-
+        cfg1 = native.default_fit_config()
+        cfg1.num_iters, cfg1.step_size = int(self.num_iters), float(self.step_size)
+        cfg1.sigma, cfg1.joint_loss_weight = _SQUARED_ERROR_SIGMA, 1.0
+        cfg1.pose_prior_weight = cfg1.angle_prior_weight = cfg1.shape_prior_weight = cfg1.pose_preserve_weight = 0.0
+        cfg1.optimize_mask, cfg1.transl_prior_weight = 9, depth_w
         # stage 2: body fit with a fresh optimiser state
-        cfg = native.default_fit_config()
-        cfg.num_iters, cfg.step_size = int(self.num_iters), float(self.step_size)
-        cfg.joint_loss_weight = float(joint_loss_weight)
-        cfg.pose_preserve_weight = float(pose_preserve_weight) if seq_ind > 0 else 0.0
-        cfg.optimize_mask = 15 if (seq_ind == 0 or not freeze_betas) else 11
-        s2 = fit(cfg, model_idx, targets, conf, s1)
+        cfg2 = native.default_fit_config()
+        cfg2.num_iters, cfg2.step_size = int(self.num_iters), float(self.step_size)
+        cfg2.joint_loss_weight = float(joint_loss_weight)
+        cfg2.pose_preserve_weight = float(pose_preserve_weight) if seq_ind > 0 else 0.0
+        fit_betas = seq_ind == 0 or not freeze_betas
+        cfg2.optimize_mask = 15 if fit_betas else 11
+        start = dict(global_orient=go, body_pose=bp, betas=be, transl=cam_t0)
+        if self.use_lbfgs:
+            s2 = self._two_stages_lbfgs(cfg1, cfg2, fit_betas, stage1_idx, stage1_tgt, model_idx, targets, conf, start, cam_t0)
+        else:
+            s1 = fit(cfg1, stage1_idx, stage1_tgt, None, start)
+            s2 = fit(cfg2, model_idx, targets, conf, s1)
 
         # loss at the fitted parameters: weight 600, no preserve term (camera_space.py:316-326)
         cfg = native.default_fit_config()
@@ -134,3 +139,46 @@ class CameraSpaceFitter:
             params=SMPLData(betas=s2["betas"], global_orient=s2["global_orient"], body_pose=s2["body_pose"],
                             transl=s2["transl"]),
             vertices=verts, joints=joints, loss=final["loss"].sum())
+
+    # ------------------------------------------------------------------------------------------------
+    def _two_stages_lbfgs(self, cfg1, cfg2, fit_betas, idx1, tgt1, idx2, tgt2, conf, start, cam_t0):
+        """LBFGS branches of both stages, frame by frame (``camera_space.py:144-182`` and ``:229-267``):
+        ``torch.optim.LBFGS(params, max_iter=num_iters, lr=step_size, line_search_fn="strong_wolfe")`` with
+        loss and gradient of every closure call from an evaluate-only launch."""
+        max_iter, lr = int(self.num_iters), float(self.step_size)
+        for cfg in (cfg1, cfg2):
+            cfg.num_iters, cfg.step_size = 1, 0.0
+        B, D = start["global_orient"].shape[0], start["body_pose"].shape[1]
+        NB = start["betas"].shape[1]
+        preserve = start["body_pose"].clone()                     # camera_space.py:136
+        rows = {k: [] for k in ("global_orient", "body_pose", "betas", "transl")}
+        for f in range(B):
+            sl = slice(f, f + 1)
+            p = {k: start[k][sl].clone() for k in rows}
+            cf = conf[sl].contiguous() if (conf is not None and conf.dim() == 2) else conf
+
+            def run(cfg, idx, tgt, cfv, opt_keys):
+                params = [p[k].requires_grad_(True) for k in opt_keys]
+                cols = {"global_orient": slice(0, 3), "body_pose": slice(3, 3 + D), "betas": slice(3 + D, 3 + D + NB),
+                        "transl": slice(3 + D + NB, 3 + D + NB + 3)}
+
+                def closure():
+                    with torch.no_grad():
+                        r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt[sl].contiguous(), cfv,
+                                             p["global_orient"].detach().contiguous(), p["body_pose"].detach().contiguous(),
+                                             p["betas"].detach().contiguous(), p["transl"].detach().contiguous(),
+                                             preserve_pose=preserve[sl].contiguous(), want_grad=True,
+                                             transl_prior_target=cam_t0[sl].contiguous())
+                    for k in opt_keys:
+                        p[k].grad = r["grad"][:, cols[k]].clone()
+                    return r["loss"].sum()
+
+                torch.optim.LBFGS(params, max_iter=max_iter, lr=lr, line_search_fn="strong_wolfe").step(closure)
+                for k in opt_keys:
+                    p[k] = p[k].detach()
+
+            run(cfg1, idx1, tgt1, None, ["global_orient", "transl"])                       # camera_space.py:142
+            run(cfg2, idx2, tgt2, cf, ["body_pose"] + (["betas"] if fit_betas else []) + ["global_orient", "transl"])  # :219-224
+            for k in rows:
+                rows[k].append(p[k].detach())
+        return {k: torch.cat(v, dim=0).contiguous() for k, v in rows.items()}

@@ -69,7 +69,8 @@ constexpr int XS = 96;                  // strip: go@0, body@4, betas@76, transl
 constexpr int XS_BODY = 4, XS_BETA = 76, XS_TRANSL = 92;
 constexpr int SLOT = 2 * XS + NC + 4;   // 260 floats: the +4 spreads the 16 frame columns of the MFMA-side reads over the banks
 constexpr int YX_STRIDE = MG * NC + 4;  // y exchange: [slot][m][64] (+4: b128 stores of the 16 frame columns hit distinct banks)
-constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE;
+constexpr int DD_STRIDE_MAX = 52;        // per-lane stride of the J_dirs table in LDS (see the kernel)
+constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX;
 static_assert(LDS_FLOATS * 4 <= 163840, "LDS budget");
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -287,6 +288,17 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     float* slots = lds + RIM_FLOATS + CMU_FLOATS;
     float* qx = slots + MAXS * SLOT;                           // [slot][m]   core part of d^T P_m d
     float* yx = qx + MAXS * MG;                                // [slot][m][64] (stride YX_STRIDE)  core part of y_m, rows 0..63
+    // J_dirs differences of every tree lane, [lane][3][NBT] at a stride that spreads the lanes' b128 reads
+    // over the banks (36 / 52 floats): 30-48 registers per lane would otherwise stay live across the loop
+    constexpr int DDN = 3 * NBT, DDQ = (DDN + 3) / 4, DD_STRIDE = 4 * DDQ + 4;
+    static_assert(DD_STRIDE <= DD_STRIDE_MAX, "LDS budget of the J_dirs table");
+    float* ddl = yx + MAXS * YX_STRIDE;
+    if (PAIR) {
+        for (int i = tid; i < 64 * DDN; i += blockDim.x) {
+            const int l = i / DDN, r = i % DDN;
+            ddl[l * DD_STRIDE + r] = a.dd[(l * 3 + r / NBT) * kMaxBetas + r % NBT];
+        }
+    }
 
     const int NB = a.num_betas;
     const int nparamB = 8 + NB + 3;            // lanes of set B that hold a parameter
@@ -358,13 +370,31 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         const int first = (lane & 32) + t, lastl = first + (sub_ok ? size - 1 : 0);
         sub_end_addr = lastl * 4;
     }
-    float dt[3], dd[3][NBT];
+    float dt[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        dt[c] = a.dt[tl * 3 + c];
+    for (int c = 0; c < 3; ++c) dt[c] = a.dt[tl * 3 + c];
+    // J_dirs differences of this lane: registers in the split / unified shapes (the LDS reads would sit on
+    // the tree's critical path), LDS in the paired shape (two frames of optimiser state per wave leave no
+    // room for 30-48 more loop-invariant registers)
+    constexpr bool DD_IN_LDS = PAIR;
+    float ddr[DD_IN_LDS ? 1 : 4 * DDQ];
+    if (!DD_IN_LDS) {
 #pragma unroll
-        for (int k = 0; k < NBT; ++k) dd[c][k] = a.dd[(tl * 3 + c) * kMaxBetas + k];
+        for (int r = 0; r < 4 * DDQ; ++r) ddr[r] = r < DDN ? a.dd[(tl * 3 + r / NBT) * kMaxBetas + r % NBT] : 0.f;
     }
+    const float4* ddl4 = reinterpret_cast<const float4*>(ddl + tl * DD_STRIDE);
+    auto read_dd = [&](float (&dd)[4 * DDQ]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < DDQ; ++q) {
+            if (DD_IN_LDS) {
+                const float4 v = ddl4[q];
+                dd[4 * q] = v.x; dd[4 * q + 1] = v.y; dd[4 * q + 2] = v.z; dd[4 * q + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dd[4 * q + e] = ddr[DD_IN_LDS ? 0 : 4 * q + e];
+            }
+        }
+    };
     const int jj = isJ ? joint : 0;
     const int thoff = jj == 0 ? 0 : XS_BODY + 3 * (jj - 1);
 
@@ -498,12 +528,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             float beta[NBT];
 #pragma unroll
             for (int k = 0; k < NBT; ++k) beta[k] = xs_t[XS_BETA + (k < NB ? k : 0)];
+            float dd[4 * DDQ];
+            read_dd(dd);
             float e[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float s = dt[c];
 #pragma unroll
-                for (int k = 0; k < NBT; ++k) s += dd[c][k] * beta[k];   // dd is zero for k >= NB
+                for (int k = 0; k < NBT; ++k) s += dd[c * NBT + k] * beta[k];   // dd is zero for k >= NB
                 e[c] = s;
             }
             dj = {e[0], e[1], e[2]};
@@ -599,10 +631,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             gth = {a1 * w.x + a2uw * rod.u.x - a3 * uxw.x, a1 * w.y + a2uw * rod.u.y - a3 * uxw.y, a1 * w.z + a2uw * rod.u.z - a3 * uxw.z};
         }
         float gb[16];
+        {
+            float dd[4 * DDQ];
+            read_dd(dd);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int kk = k < NBT ? k : 0;
-            gb[k] = (isJ && k < NBT) ? gd.x * dd[0][kk] + gd.y * dd[1][kk] + gd.z * dd[2][kk] : 0.f;
+            for (int k = 0; k < 16; ++k) {
+                const int kk = k < NBT ? k : 0;
+                gb[k] = (isJ && k < NBT) ? gd.x * dd[kk] + gd.y * dd[NBT + kk] + gd.z * dd[2 * NBT + kk] : 0.f;
+            }
         }
         // d joint-loss / d beta_k summed over the tree; which lane ends up with which k: see the helpers
         const float gbeta = PAIR ? butterfly16_half_sum(gb, lane) : butterfly16_sum(gb, lane);
@@ -767,9 +803,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             __syncthreads();
             floatx4 ya[4];
             if (use_gmm) comp_issue(pa_h, pa_l, ya);
-            if (do_row) rim();
-            if (do_tree) tree_pass(last);
-            if (use_gmm) comp_consume(ya, wave);
+            if (do_row) rim();                          // the matrix pipe runs under the rim's vector work ...
+            if (PAIR) {
+                if (use_gmm) comp_consume(ya, wave);    // paired: consume before the tree, whose registers are then free
+                if (do_tree) tree_pass(last);
+            } else {
+                if (do_tree) tree_pass(last);           // ... and under the tree
+                if (use_gmm) comp_consume(ya, wave);
+            }
             __syncthreads();
             if (do_row) row_update(it, last);
         }

@@ -316,6 +316,47 @@ def main():
             out_verts_sampled=cat(outs["verts_sampled"]), sampled_vertex_ids=sample_vertex_ids(6890))
         print(f"[golden] camera {name}: iters={iters} losses={cat(outs['loss'])}")
 
+    # ---- LBFGS branch of the camera-space fitter ---------------------------------------------------------
+    for name, iters, seq_ind, freeze in (("first", 20, 0, False), ("followup_frozen", 10, 3, True)):
+        fitter = CameraSpaceFitter(model, step_size=1e-2, num_iters=iters, use_lbfgs=True,
+                                   joints_category="AMASS", device=torch.device("cpu"))
+        outs = {k: [] for k in ("go", "bp", "be", "tr", "joints", "loss", "t0")}
+        n = 3
+        gen = torch.Generator().manual_seed(4321)
+        pert, pdev, jdev = (np.zeros((n, 10), np.float32) for _ in range(3))
+        for i in range(n):
+            sl = slice(i, i + 1)
+            with torch.no_grad():
+                j0 = model(global_orient=init3["global_orient"][sl], body_pose=init3["body_pose"][sl],
+                           betas=init3["betas"][sl]).joints
+            t0 = guess_init_3d(j0, noisy22[sl], "AMASS") + off
+            outs["t0"].append(t0)
+            call = lambda go, bp, t: fitter.fit_frame(
+                SMPLData(betas=init3["betas"][sl], global_orient=go, body_pose=bp), noisy22[sl], conf_3d=conf,
+                seq_ind=seq_ind, joint_loss_weight=600.0, pose_preserve_weight=5.0, freeze_betas=freeze, init_cam_t=t)
+            res = call(init3["global_orient"][sl], init3["body_pose"][sl], t0)
+            p = res.params
+            outs["go"].append(p.global_orient); outs["bp"].append(p.body_pose); outs["be"].append(p.betas)
+            outs["tr"].append(p.transl); outs["joints"].append(res.joints); outs["loss"].append(res.loss.reshape(1))
+            jerr0 = (res.joints[:, :22] + p.transl[:, None] - noisy22[sl]).norm(dim=-1).mean()
+            for trial in range(10):        # the reference's own spread under rounding-level perturbations (see the world LBFGS cases)
+                nz = lambda x: x * (1 + 2e-6 * torch.randn(x.shape, generator=gen))
+                rp = call(nz(init3["global_orient"][sl]), nz(init3["body_pose"][sl]), nz(t0))
+                pert[i, trial] = float(rp.loss)
+                pdev[i, trial] = max(float((getattr(rp.params, k) - getattr(p, k)).abs().max())
+                                     for k in ("global_orient", "body_pose", "betas", "transl"))
+                jdev[i, trial] = abs(float((rp.joints[:, :22] + rp.params.transl[:, None] - noisy22[sl]).norm(dim=-1).mean() - jerr0))
+        cat = lambda xs: torch.cat(xs, dim=0).detach().numpy()
+        np.savez_compressed(
+            GOLDEN / f"lbfgs_camera_{name}.npz", case=name, seq_ind=seq_ind, max_iter=iters, freeze_betas=int(freeze),
+            conf=conf.numpy(), j3d=noisy22[:n].numpy(), init_cam_t=cat(outs["t0"]),
+            init_global_orient=init3["global_orient"][:n].numpy(), init_body_pose=init3["body_pose"][:n].numpy(),
+            init_betas=init3["betas"][:n].numpy(),
+            out_global_orient=cat(outs["go"]), out_body_pose=cat(outs["bp"]), out_betas=cat(outs["be"]),
+            out_transl=cat(outs["tr"]), out_loss=cat(outs["loss"]), out_joints=cat(outs["joints"]), out_loss_perturbed=pert,
+            out_param_dev_perturbed=pdev, out_joint_err_dev_perturbed=jdev)
+        print(f"[golden] camera lbfgs {name}: losses={cat(outs['loss'])} spread={pert.min(1)}..{pert.max(1)}")
+
     # ---- LBFGS branch of the world fitter (the reference's default) --------------------------------------
     WorldSpaceFitter = ref[0]
     for name, seq_ind, iters, freeze in (("first", 0, 30, False), ("followup", 4, 10, False), ("frozen", 0, 15, True)):

@@ -157,6 +157,44 @@ def test_camera_space_fitter_matches_reference_golden(assets, case):
         assert np.abs(r1.params.transl.cpu().numpy() - d["out_transl"][:1]).max() < tol
 
 
+@pytest.mark.parametrize("case", ["first", "followup_frozen"])
+def test_lbfgs_camera_fit_matches_reference_golden(assets, case):
+    """LBFGS branches of the camera-space fitter (both stages).  Same statistical gate as the world LBFGS
+    mode below: median final loss of five rounding-level-perturbed runs inside the reference's own envelope
+    (``out_loss_perturbed``); closest run's parameters and the median joint error inside the deviations the
+    reference shows against itself (``out_param_dev_perturbed``, ``out_joint_err_dev_perturbed``)."""
+    from keypoints2body_amd.core.fitters.camera_space import CameraSpaceFitter
+    model, prior = assets
+    d = dict(np.load(H.GOLDEN / f"lbfgs_camera_{case}.npz"))
+    fitter = CameraSpaceFitter(model, step_size=1e-2, num_iters=int(d["max_iter"]), use_lbfgs=True,
+                               joints_category="AMASS", pose_prior=prior)
+    gen = torch.Generator().manual_seed(11)
+    for i in range(d["j3d"].shape[0]):
+        t = lambda k: torch.tensor(d[k][i:i + 1])
+        losses, perr, jerr = [], [], []
+        for trial in range(5):
+            nz = (lambda x: x) if trial == 0 else (lambda x: x * (1 + 2e-6 * torch.randn(x.shape, generator=gen)))
+            res = fitter.fit_frame(k2b.SMPLData(betas=t("init_betas"), global_orient=nz(t("init_global_orient")),
+                                                body_pose=nz(t("init_body_pose"))),
+                                   t("j3d"), conf_3d=torch.tensor(d["conf"]), seq_ind=int(d["seq_ind"]),
+                                   freeze_betas=bool(int(d["freeze_betas"])), init_cam_t=nz(t("init_cam_t")))
+            losses.append(float(res.loss))
+            perr.append(max(np.abs(getattr(res.params, key).cpu().numpy() - d["out_" + key][i:i + 1]).max()
+                            for key in ("global_orient", "body_pose", "betas", "transl")))
+            mine = (res.joints[:, :22].cpu() + res.params.transl.cpu()[:, None] - t("j3d")).norm(dim=-1).mean()
+            ref = (torch.tensor(d["out_joints"][i:i + 1, :22]) + t("out_transl")[:, None] - t("j3d")).norm(dim=-1).mean()
+            jerr.append(abs(float(mine) - float(ref)))
+        env = np.concatenate([d["out_loss_perturbed"][i], d["out_loss"][i:i + 1]])
+        med = float(np.median(losses))
+        assert 0.85 * env.min() <= med <= 1.15 * env.max(), (case, i, losses, env)
+        # parameters and joint error: inside what the reference does to ITSELF under the same perturbation
+        # (largest deviation of its ten perturbed runs from its unperturbed one, widened by 25 %)
+        assert min(perr) < max(5e-2, 1.25 * float(d["out_param_dev_perturbed"][i].max())), (case, i, perr)
+        assert float(np.median(jerr)) < max(1e-2, 1.25 * float(d["out_joint_err_dev_perturbed"][i].max())), (case, i, jerr)
+        if int(d["seq_ind"]) > 0 and int(d["freeze_betas"]):
+            assert torch.equal(res.params.betas.cpu(), t("init_betas"))
+
+
 @pytest.mark.parametrize("case", ["first", "followup", "frozen"])
 def test_lbfgs_world_fit_matches_reference_golden(assets, case):
     """use_lbfgs=True (the reference's default): torch.optim.LBFGS drives evaluate-only launches of

@@ -1,13 +1,16 @@
 """Launch the fused fit a few times at a given batch (for rocprofv3 --pmc passes and quick timing).
-usage: python3 tools/dev_fit_once.py FRAMES [pose_prior_weight] [launches]"""
+usage: python3 tools/dev_fit_once.py FRAMES [pose_prior_weight|-] [launches] [lib variant: tools/libk2b_<name>.so]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from tests import helpers as H
 from keypoints2body_amd import native, synthetic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-wpp = float(sys.argv[2]) if len(sys.argv) > 2 else None
+wpp = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != '-' else None
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+if len(sys.argv) > 4:
+    from pathlib import Path
+    native._LIB_PATH = Path(__file__).resolve().parent / f'libk2b_{sys.argv[4]}.so'
 m, pr = H.native_model(), H.native_prior()
 p = synthetic.make_poses(B, seed=1)
 go, bp, be, tr = map(H.cuda, (p.global_orient, p.body_pose, p.betas, p.transl))
@@ -24,4 +27,4 @@ ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
 for _ in range(n): o = run()
 ev[1].record(); torch.cuda.synchronize()
-print(f'B={B} wpp={wpp}: fit {ev[0].elapsed_time(ev[1]) / n:.4f} ms  loss mean {o["loss"].mean().item():.2f}')
+print(f'{sys.argv[4] if len(sys.argv) > 4 else "head"} B={B} wpp={wpp}: fit {ev[0].elapsed_time(ev[1]) / n:.4f} ms  loss mean {o["loss"].mean().item():.2f}')
