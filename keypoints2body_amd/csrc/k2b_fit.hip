@@ -113,14 +113,14 @@ __device__ __forceinline__ float bperm(int byte_addr, float v) {
 // ---- LDS-free cross-lane exchanges (gfx950) ------------------------------------------------------
 // v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
 // (Inline asm: the clang builtin of ROCm 7.2 returns the updated first register in BOTH result
-//  elements - tools/probe/lanes.hip.  The s_nop covers the VALU-write -> cross-lane-read wait states
-//  hipcc does not insert inside asm.)
+//  elements - tools/probe/lanes.hip.  The s_nop covers the two wait states between a VALU write of an
+//  operand and the swap reading it, which hipcc does not insert inside asm.)
 __device__ __forceinline__ void swap32(float& a, float& b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 // v_permlane16_swap: the odd 16-lane rows of `a` trade places with the even rows of `b`.
 __device__ __forceinline__ void swap16(float& a, float& b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
