@@ -70,7 +70,8 @@ constexpr int XS_BODY = 4, XS_BETA = 76, XS_TRANSL = 92;
 constexpr int SLOT = 2 * XS + NC + 4;   // 260 floats: the +4 spreads the 16 frame columns of the MFMA-side reads over the banks
 constexpr int YX_STRIDE = MG * NC + 4;  // y exchange: [slot][m][64] (+4: b128 stores of the 16 frame columns hit distinct banks)
 constexpr int DD_STRIDE_MAX = 52;        // per-lane stride of the J_dirs table in LDS (see the kernel)
-constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX;
+constexpr int PLO_FLOATS = MG * 4 * 2 * 64 * 4;   // lo fragments of all components (paired shape): [m][tile][ks][64 lanes][8 halfs]
+constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX + PLO_FLOATS;
 static_assert(LDS_FLOATS * 4 <= 163840, "LDS budget");
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     constexpr int DDN = 3 * NBT, DDQ = (DDN + 3) / 4, DD_STRIDE = 4 * DDQ + 4;
     static_assert(DD_STRIDE <= DD_STRIDE_MAX, "LDS budget of the J_dirs table");
     float* ddl = yx + MAXS * YX_STRIDE;
+    half8* plo = reinterpret_cast<half8*>(ddl + 64 * DD_STRIDE_MAX);   // paired shape: lo fragments, [m][tile][ks][lane]
     if (PAIR) {
         for (int i = tid; i < 64 * DDN; i += blockDim.x) {
             const int l = i / DDN, r = i % DDN;
@@ -462,7 +464,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // ---- c. GMM prior, 64 x 64 core of one component for every frame slot: three f16 MFMA products ----
     // (small terms first; the results are consumed later in the iteration, so the matrix pipe runs under
     //  the vector work issued in between)
-    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&pl)[4][2], floatx4 (&yacc)[4]) __attribute__((always_inline)) {
+    // (paired shape: the lo fragments are read from LDS each iteration instead of occupying 32 registers
+    //  next to two frames of optimiser state)
+    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&plr)[4][2], floatx4 (&yacc)[4]) __attribute__((always_inline)) {
+        half8 pl[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pl[t][ks] = PAIR ? plo[((wave * 4 + t) * 2 + ks) * 64 + lane] : plr[t][ks];
         const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
         const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
         const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
@@ -797,6 +806,12 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         // unified / paired: every wave carries component `wave` and the row and tree roles of its slot(s)
         half8 pa_h[4][2], pa_l[4][2];
         load_frags(wave, pa_h, pa_l);
+        if (PAIR) {          // park the lo fragments in LDS (visible after the first barrier of the loop)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) plo[((wave * 4 + t) * 2 + ks) * 64 + lane] = pa_l[t][ks];
+        }
         for (int it = 0; it < a.num_iters; ++it) {
             const bool last = it == a.num_iters - 1;
             if (do_row) publish();
