@@ -251,12 +251,15 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     constexpr bool SPLIT = MODE == MODE_SPLIT, PAIR = MODE == MODE_PAIRED;
     constexpr int FW = PAIR ? 2 : 1;         // frames a wave carries in its row and tree roles
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ int row_sync_cell;                    // split shape: meeting point of the four row waves
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;               // always 8 waves: wave w also owns mixture component w
     const int M = a.num_gauss;
     const int F = a.frames_per_wg;           // frame slots of this workgroup (split <= 4, unified <= 8, paired <= 16)
+    int* row_sync = &row_sync_cell;
+    if (tid == 0) *row_sync = 0;                 // visible to every wave after the first barrier of the loop
 
     // ---- 0. rim of the precisions, mu and c of the core rows -> LDS (shared by the workgroup) ----------
     {
@@ -685,13 +688,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         if (cg == 0 && cn < F) qx[cn * MG + comp] = qp;
     };
 
-    auto row_update = [&](int it, bool last) __attribute__((always_inline)) {
+    // ---- row role, part 1 (needs y and q of every component, not the tree): arg-min component, its y in
+    // row layout, and every prior's share of the gradient and of the loss ---------------------------------
+    float gp0[FW], gp1[FW], lossp[FW], bestv[FW];
+    auto row_prior = [&](bool last) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
         const int slot = slot0 + h;
         const float* xs = slots + slot * SLOT;
-        const float* gs_r = xs + XS;
-        // ---- arg-min component of this frame, its y in row layout --------------------------------------
         float yA = 0.f, yBs = 0.f, best = 0.f;
         if (use_gmm) {
             const float q = qrim[h] + qx[slot * MG + gm];        // lanes 8m..8m+7: d^T P d of component m
@@ -711,35 +715,39 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             yA += rimf[0 * 512] * t64.x + rimf[1 * 512] * t64.y + rimf[2 * 512] * t64.z + rimf[3 * 512] * t64.w + rimf[4 * 512] * t68;
             yBs = bperm((8 * mstar + (lane < NR ? lane : 0)) * 4, yB[h]);   // rows 64 + lane for lanes < 5
         }
-        // ---- row layout: gradients of the joint term, then the priors ---------------------------------
-        g0[h] = gs_r[offA];
-        g1[h] = actB ? gs_r[offB] : 0.f;
-        const float jloss = gs_r[XS - 1];
         float part = 0.f;                  // per-lane partial of the prior losses
-        {
-            g0[h] += wpp2 * yA + 2.f * wpr2 * (x0[h] - pr0[h]);
-            if (angA != 0.f) {
-                const float e = __expf(x0[h] * angA);
-                g0[h] += wa2 * 2.f * angA * e * e;
-                if (last) part += wa2 * e * e;
-            }
-            if (last) part += wpr2 * (x0[h] - pr0[h]) * (x0[h] - pr0[h]);
+        float ga = wpp2 * yA + 2.f * wpr2 * (x0[h] - pr0[h]), gb = 0.f;
+        if (angA != 0.f) {
+            const float e = __expf(x0[h] * angA);
+            ga += wa2 * 2.f * angA * e * e;
+            if (last) part += wa2 * e * e;
         }
+        if (last) part += wpr2 * (x0[h] - pr0[h]) * (x0[h] - pr0[h]);
         if (bodyB) {
-            g1[h] += wpp2 * yBs + 2.f * wpr2 * (x1[h] - pr1[h]);
+            gb = wpp2 * yBs + 2.f * wpr2 * (x1[h] - pr1[h]);
             if (last) part += wpr2 * (x1[h] - pr1[h]) * (x1[h] - pr1[h]);
         }
         if (betaB) {
-            g1[h] += 2.f * ws2 * x1[h];
+            gb = 2.f * ws2 * x1[h];
             if (last) part += ws2 * x1[h] * x1[h];
         }
         if (translB) {
-            g1[h] += 2.f * wt2 * (x1[h] - tp1[h]);
+            gb = 2.f * wt2 * (x1[h] - tp1[h]);
             if (last) part += wt2 * (x1[h] - tp1[h]) * (x1[h] - tp1[h]);
         }
-        if (last) loss_total[h] = wave_sum_fast(part) + wpp2 * best + jloss;
+        gp0[h] = ga; gp1[h] = gb; lossp[h] = part; bestv[h] = best;
+        }  // frames of this wave
+    };
+    // ---- row role, part 2 (after the tree): add the joint term's gradient, Adam ------------------------------
+    auto row_finish = [&](int it, bool last) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < FW; ++h) {
+        const float* gs_r = slots + (slot0 + h) * SLOT + XS;
+        g0[h] = gs_r[offA] + gp0[h];
+        g1[h] = actB ? gs_r[offB] + gp1[h] : 0.f;
+        if (last) loss_total[h] = wave_sum_fast(lossp[h]) + wpp2 * bestv[h] + gs_r[XS - 1];
 
-        // ---- g. Adam (torch.optim.Adam, single-tensor path) ------------------------------------------
+        // torch.optim.Adam, single-tensor path
         const float2 co = a.adam_coef[it];     // {lr / (1 - b1^t), sqrt(1 - b2^t)}
         const float inv_bc2 = fast_rcp(co.y);
         if (optA) {
@@ -798,9 +806,17 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             if (use_gmm) {
                 comp_consume(ya, wave);
                 comp_consume(yb, wave + 4);
+                // the four row waves hold all eight components between them: they meet at an LDS counter
+                // (release after their y / q writes, acquire before reading the others') so that the
+                // arg-min and the priors' gradient are done while the tree waves still work, and only
+                // "add the joint gradient, Adam, publish" is left on the iteration's critical path
+                if (lane == 0) __hip_atomic_fetch_add(row_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int target = 4 * (it + 1);
+                while (__hip_atomic_load(row_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
+            if (do_row) row_prior(last);
             __syncthreads();
-            if (do_row) row_update(it, last);
+            if (do_row) row_finish(it, last);
         }
     } else {
         // unified / paired: every wave carries component `wave` and the row and tree roles of its slot(s)
@@ -827,7 +843,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 if (use_gmm) comp_consume(ya, wave);
             }
             __syncthreads();
-            if (do_row) row_update(it, last);
+            if (do_row) {
+                row_prior(last);
+                row_finish(it, last);
+            }
         }
     }
     if (!do_row) return;
