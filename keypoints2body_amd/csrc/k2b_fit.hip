@@ -469,12 +469,13 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     //  the vector work issued in between)
     // (paired shape: the lo fragments are read from LDS each iteration instead of occupying 32 registers
     //  next to two frames of optimiser state)
-    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&plr)[4][2], floatx4 (&yacc)[4]) __attribute__((always_inline)) {
+    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&plr)[4][2], floatx4 (&yacc)[4], int lds_comp) __attribute__((always_inline)) {
+        // lds_comp >= 0: the lo fragments of that component are read from LDS instead of registers
         half8 pl[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) pl[t][ks] = PAIR ? plo[((wave * 4 + t) * 2 + ks) * 64 + lane] : plr[t][ks];
+            for (int ks = 0; ks < 2; ++ks) pl[t][ks] = lds_comp >= 0 ? plo[((lds_comp * 4 + t) * 2 + ks) * 64 + lane] : plr[t][ks];
         const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
         const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
         const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
@@ -790,17 +791,23 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     }
     if (SPLIT) {
         // row waves: optimiser state of slot `wave`, mixture components `wave` and `wave + 4`
+        // (the lo fragments of the second component are parked in LDS: 96 instead of 128 resident registers,
+        //  which keeps this loop free of scratch spills)
         half8 pa_h[4][2], pa_l[4][2], pb_h[4][2], pb_l[4][2];
         load_frags(wave, pa_h, pa_l);
         load_frags(wave + 4, pb_h, pb_l);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) plo[(((wave + 4) * 4 + t) * 2 + ks) * 64 + lane] = pb_l[t][ks];
         for (int it = 0; it < a.num_iters; ++it) {
             const bool last = it == a.num_iters - 1;
             if (do_row) publish();
             __syncthreads();
             floatx4 ya[4], yb[4];
             if (use_gmm) {
-                comp_issue(pa_h, pa_l, ya);
-                comp_issue(pb_h, pb_l, yb);
+                comp_issue(pa_h, pa_l, ya, -1);
+                comp_issue(pb_h, pb_l, yb, wave + 4);
             }
             if (do_row) rim();
             if (use_gmm) {
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             if (do_row) publish();
             __syncthreads();
             floatx4 ya[4];
-            if (use_gmm) comp_issue(pa_h, pa_l, ya);
+            if (use_gmm) comp_issue(pa_h, pa_l, ya, PAIR ? wave : -1);
             if (do_row) rim();                          // the matrix pipe runs under the rim's vector work ...
             if (PAIR) {
                 if (use_gmm) comp_consume(ya, wave);    // paired: consume before the tree, whose registers are then free
