@@ -29,12 +29,13 @@
 // The layouts exchange values through per-frame LDS strips.
 //
 // Three execution shapes (template parameter MODE), chosen by frames per CU:
-//   split    <= 4 frames per CU: each frame gets TWO waves on one SIMD, the "row" wave (rim of the
-//            prior, Adam, owns the optimiser state) and the "tree" wave (kinematics, joint loss,
-//            analytic backward), so the critical path of an iteration is the tree alone;
-//   unified  <= 8: one wave does both for its frame;
-//   paired   <= 16: one wave does both for TWO frames; the two trees share the wave (one per 32-lane
-//            half), which halves the tree instructions per frame.
+//   split         <= 4 frames per CU: each frame gets TWO waves on one SIMD, the "row" wave (two mixture
+//                 components, rim of the prior, Adam; owns the optimiser state) and the "tree" wave
+//                 (kinematics, joint loss, analytic backward), in separate specialised loops, so the
+//                 critical path of an iteration is the tree alone;
+//   split-paired  <= 8: the same, with two frames per row wave and both their trees in one pass of the
+//                 tree wave (one tree per 32-lane half);
+//   paired        <= 16: wave w does everything for frames 2w and 2w + 1 and carries component w.
 // Every wave of the workgroup meets at two barriers per iteration (parameters published /
 // gradients, y and q published), in every shape.
 //
@@ -244,11 +245,11 @@ __device__ __forceinline__ float butterfly16_half_sum(const float (&v)[16], int 
 
 }  // namespace
 
-enum { MODE_SPLIT = 0, MODE_UNIFIED = 1, MODE_PAIRED = 2 };
+enum { MODE_SPLIT = 0, MODE_SPLIT_PAIRED = 1, MODE_PAIRED = 2 };
 
 template <int NBT, int MODE>
 __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs a) {
-    constexpr bool SPLIT = MODE == MODE_SPLIT, PAIR = MODE == MODE_PAIRED;
+    constexpr bool SPLIT = MODE == MODE_SPLIT || MODE == MODE_SPLIT_PAIRED, PAIR = MODE == MODE_PAIRED || MODE == MODE_SPLIT_PAIRED;
     constexpr int FW = PAIR ? 2 : 1;         // frames a wave carries in its row and tree roles
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ int row_sync_cell;                    // split shape: meeting point of the four row waves
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const int lane = tid & 63;
     const int wave = tid >> 6;               // always 8 waves: wave w also owns mixture component w
     const int M = a.num_gauss;
-    const int F = a.frames_per_wg;           // frame slots of this workgroup (split <= 4, unified <= 8, paired <= 16)
+    const int F = a.frames_per_wg;           // frame slots of this workgroup (split <= 4, split-paired <= 8, paired <= 16)
     int* row_sync = &row_sync_cell;
     if (tid == 0) *row_sync = 0;                 // visible to every wave after the first barrier of the loop
 
@@ -271,10 +272,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // frame slots and roles of this wave
     //   split    waves 0..3 are the row waves of slots 0..3, waves 4..7 their tree waves (waves w and
     //            w + 4 share a SIMD, so every SIMD hosts one row wave and one tree wave);
-    //   unified  wave w does both for slot w;
-    //   paired   wave w does both for slots 2w and 2w + 1: the tree of slot 2w lives in lanes 0..31,
-    //            that of slot 2w + 1 in lanes 32..63; the row work runs once per slot.
-    const int slot0 = SPLIT ? (wave & 3) : (PAIR ? 2 * wave : wave);
+    //   paired   two frame slots per wave (2w, 2w + 1): the tree of the first lives in lanes 0..31, that of
+    //            the second in lanes 32..63; the row work runs once per slot.  Without split, wave w does
+    //            both roles for its two slots.
+    const int slot0 = (PAIR ? 2 : 1) * (SPLIT ? (wave & 3) : wave);
     const bool do_row = slot0 < F && (!SPLIT || wave < 4);     // rim of the prior, priors in row layout, Adam, results
     const bool do_tree = slot0 < F && (!SPLIT || wave >= 4);   // kinematics, joint loss, analytic backward
     // every wave must reach every barrier: a padding slot recomputes the last frame and skips the final stores
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     static_assert(DD_STRIDE <= DD_STRIDE_MAX, "LDS budget of the J_dirs table");
     float* ddl = yx + MAXS * YX_STRIDE;
     half8* plo = reinterpret_cast<half8*>(ddl + 64 * DD_STRIDE_MAX);   // paired shape: lo fragments, [m][tile][ks][lane]
-    if (PAIR) {
+    if (PAIR && !SPLIT) {
         for (int i = tid; i < 64 * DDN; i += blockDim.x) {
             const int l = i / DDN, r = i % DDN;
             ddl[l * DD_STRIDE + r] = a.dd[(l * 3 + r / NBT) * kMaxBetas + r % NBT];
@@ -378,10 +379,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     float dt[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) dt[c] = a.dt[tl * 3 + c];
-    // J_dirs differences of this lane: registers in the split / unified shapes (the LDS reads would sit on
+    // J_dirs differences of this lane: registers in the split shapes (the LDS reads would sit on
     // the tree's critical path), LDS in the paired shape (two frames of optimiser state per wave leave no
     // room for 30-48 more loop-invariant registers)
-    constexpr bool DD_IN_LDS = PAIR;
+    constexpr bool DD_IN_LDS = PAIR && !SPLIT;
     float ddr[DD_IN_LDS ? 1 : 4 * DDQ];
     if (!DD_IN_LDS) {
 #pragma unroll
@@ -799,14 +800,17 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) plo[(((wave + 4) * 4 + t) * 2 + ks) * 64 + lane] = pb_l[t][ks];
+            for (int ks = 0; ks < 2; ++ks) {
+                plo[(((wave + 4) * 4 + t) * 2 + ks) * 64 + lane] = pb_l[t][ks];
+                if (PAIR) plo[((wave * 4 + t) * 2 + ks) * 64 + lane] = pa_l[t][ks];   // two frames of optimiser state: both
+            }
         for (int it = 0; it < a.num_iters; ++it) {
             const bool last = it == a.num_iters - 1;
             if (do_row) publish();
             __syncthreads();
             floatx4 ya[4], yb[4];
             if (use_gmm) {
-                comp_issue(pa_h, pa_l, ya, -1);
+                comp_issue(pa_h, pa_l, ya, PAIR ? wave : -1);
                 comp_issue(pb_h, pb_l, yb, wave + 4);
             }
             if (do_row) rim();
@@ -826,10 +830,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             if (do_row) row_finish(it, last);
         }
     } else {
-        // unified / paired: every wave carries component `wave` and the row and tree roles of its slot(s)
+        // paired: every wave carries component `wave` and the row and tree roles of its two slots
         half8 pa_h[4][2], pa_l[4][2];
         load_frags(wave, pa_h, pa_l);
-        if (PAIR) {          // park the lo fragments in LDS (visible after the first barrier of the loop)
+        {                    // park the lo fragments in LDS (visible after the first barrier of the loop)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -840,15 +844,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             if (do_row) publish();
             __syncthreads();
             floatx4 ya[4];
-            if (use_gmm) comp_issue(pa_h, pa_l, ya, PAIR ? wave : -1);
-            if (do_row) rim();                          // the matrix pipe runs under the rim's vector work ...
-            if (PAIR) {
-                if (use_gmm) comp_consume(ya, wave);    // paired: consume before the tree, whose registers are then free
-                if (do_tree) tree_pass(last);
-            } else {
-                if (do_tree) tree_pass(last);           // ... and under the tree
-                if (use_gmm) comp_consume(ya, wave);
-            }
+            if (use_gmm) comp_issue(pa_h, pa_l, ya, wave);
+            if (do_row) rim();                          // the matrix pipe runs under the rim's vector work
+            if (use_gmm) comp_consume(ya, wave);        // consumed before the tree, whose registers are then free
+            if (do_tree) tree_pass(last);
             __syncthreads();
             if (do_row) {
                 row_prior(last);
@@ -887,28 +886,28 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     // (SIMDs would idle, so every frame gets two cooperating waves); up to 8: one wave per frame;
     // beyond: two frames per wave.
     int fpw = (a.num_frames + a.num_cus - 1) / a.num_cus;
-    int mode = fpw <= 4 ? MODE_SPLIT : (fpw <= MAXW ? MODE_UNIFIED : MODE_PAIRED);
-    // test hook: K2B_FIT_MODE=split|unified|paired forces a shape regardless of the batch size, so that
+    int mode = fpw <= 4 ? MODE_SPLIT : (fpw <= MAXW ? MODE_SPLIT_PAIRED : MODE_PAIRED);
+    // test hook: K2B_FIT_MODE=split|split_paired|paired forces a shape regardless of the batch size, so that
     // the parity tests can drive every shape with the small golden cases
     if (const char* force = getenv("K2B_FIT_MODE")) {
         if (!strcmp(force, "split")) mode = MODE_SPLIT;
-        else if (!strcmp(force, "unified")) mode = MODE_UNIFIED;
+        else if (!strcmp(force, "split_paired")) mode = MODE_SPLIT_PAIRED;
         else if (!strcmp(force, "paired")) mode = MODE_PAIRED;
-        fpw = mode == MODE_SPLIT ? 4 : (mode == MODE_UNIFIED ? MAXW : MAXS);
+        fpw = mode == MODE_SPLIT ? 4 : (mode == MODE_PAIRED ? MAXS : MAXW);
         if (fpw > a.num_frames) fpw = a.num_frames;
     }
-    const int cap = mode == MODE_SPLIT ? 4 : (mode == MODE_UNIFIED ? MAXW : MAXS);
+    const int cap = mode == MODE_SPLIT ? 4 : (mode == MODE_PAIRED ? MAXS : MAXW);
     fpw = fpw < 1 ? 1 : (fpw > cap ? cap : fpw);
     a.frames_per_wg = fpw;
     const dim3 grid((a.num_frames + fpw - 1) / fpw), block(MAXW * 64);   // always 8 waves: wave w carries mixture component w
 #define K2B_LAUNCH(NBT_, MODE_) hipLaunchKernelGGL((k2b_fit_world_kernel<NBT_, MODE_>), grid, block, 0, stream, a)
     if (a.num_betas <= 10) {
         if (mode == MODE_SPLIT) K2B_LAUNCH(10, MODE_SPLIT);
-        else if (mode == MODE_UNIFIED) K2B_LAUNCH(10, MODE_UNIFIED);
+        else if (mode == MODE_SPLIT_PAIRED) K2B_LAUNCH(10, MODE_SPLIT_PAIRED);
         else K2B_LAUNCH(10, MODE_PAIRED);
     } else {
         if (mode == MODE_SPLIT) K2B_LAUNCH(16, MODE_SPLIT);
-        else if (mode == MODE_UNIFIED) K2B_LAUNCH(16, MODE_UNIFIED);
+        else if (mode == MODE_SPLIT_PAIRED) K2B_LAUNCH(16, MODE_SPLIT_PAIRED);
         else K2B_LAUNCH(16, MODE_PAIRED);
     }
 #undef K2B_LAUNCH

@@ -116,10 +116,10 @@ def test_fit_matches_reference_golden(case):
     print(f"{case}: worst parameter deviation over the trace = {worst:.2e}")
 
 
-@pytest.mark.parametrize("shape", ["split", "unified", "paired"])
+@pytest.mark.parametrize("shape", ["split", "split_paired", "paired"])
 def test_every_launch_shape_matches_reference_golden(shape, monkeypatch):
-    """The fit kernel has three launch shapes chosen by frames per CU (two waves per frame, one wave per
-    frame, two frames per wave).  K2B_FIT_MODE forces a shape so that each one is pinned to the reference
+    """The fit kernel has three launch shapes chosen by frames per CU (row + tree wave per frame, row + tree
+    wave per two frames, one wave for two frames).  K2B_FIT_MODE forces a shape so that each one is pinned to the reference
     goldens, including a ragged batch that leaves half a paired wave and several MFMA columns empty."""
     monkeypatch.setenv("K2B_FIT_MODE", shape)
     for case in ("amass_batched", "amass_followup", "smpl24_zero_init"):
@@ -131,8 +131,7 @@ def test_every_launch_shape_matches_reference_golden(shape, monkeypatch):
 
 
 def test_launch_shapes_agree_bitwise_on_a_ragged_batch(monkeypatch):
-    """Same arithmetic in every shape: loss and gradient of 37 frames (2 workgroups + a ragged tail in
-    the paired shape) are bit-identical across shapes."""
+    """Same arithmetic in every shape: loss and gradient of 37 frames (up to 10 workgroups with ragged tails) are bit-identical across shapes."""
     from keypoints2body_amd import native, synthetic
     B = 37
     m, pr = H.native_model(), H.native_prior()
@@ -142,10 +141,10 @@ def test_launch_shapes_agree_bitwise_on_a_ragged_batch(monkeypatch):
     j3d = (j[:, :22] + 0.01).contiguous()
     cfg = native.default_fit_config(); cfg.num_iters = 3
     res = {}
-    for shape in ("split", "unified", "paired"):
+    for shape in ("split", "split_paired", "paired"):
         monkeypatch.setenv("K2B_FIT_MODE", shape)
         res[shape] = native.fit_world(m, pr, cfg, list(range(22)), j3d, None, go * 0.9, bp * 0.9, be * 0.5, tr, want_grad=True)
-    for shape in ("unified", "paired"):
+    for shape in ("split_paired", "paired"):
         for k in ("global_orient", "body_pose", "betas", "transl", "loss", "grad"):
             assert torch.equal(res["split"][k], res[shape][k]), f"{shape}: {k}"
 

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 from tests import helpers as H
-for mode in ('split', 'unified', 'paired'):
+for mode in ('split', 'split_paired', 'paired'):
     os.environ['K2B_FIT_MODE'] = mode
     worst = 0.0
     for case in H.WORLD_CASES:

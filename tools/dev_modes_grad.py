@@ -1,4 +1,4 @@
-"""Compare loss/gradient of the fit-kernel shapes against the unified one (evaluate-only launches)."""
+"""Compare loss/gradient of the fit-kernel shapes against the split one (evaluate-only launches)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
@@ -12,12 +12,12 @@ for B in (1, 2, 3, 5, 17, 40):
     j3d = (j[:, :22] + 0.01).contiguous()
     cfg = native.default_fit_config(); cfg.num_iters = 1; cfg.step_size = 0.0
     res = {}
-    for mode in ('unified', 'split', 'paired'):
+    for mode in ('split', 'split_paired', 'paired'):
         os.environ['K2B_FIT_MODE'] = mode
         o = native.fit_world(m, pr, cfg, list(range(22)), j3d, None, go * 0.9, bp * 0.9, be * 0.5, tr, want_grad=True)
         res[mode] = (o['loss'].cpu().numpy(), o['grad'].cpu().numpy())
-    l0, g0 = res['unified']
-    for mode in ('split', 'paired'):
+    l0, g0 = res['split']
+    for mode in ('split_paired', 'paired'):
         l, g = res[mode]
         d = np.abs(g - g0)
         sc = np.abs(g0).max()
