@@ -402,11 +402,19 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
                     }
             }
     }
-    HIP_TRY(upload(&p->pa_image, pa.data(), pa.size()));
-    HIP_TRY(upload(&p->row_const, rc.data(), rc.size()));
-    HIP_TRY(upload(&p->nlw, nlw.data(), nlw.size()));
-    HIP_TRY(hipMalloc((void**)&p->frag32, f32.size() * sizeof(k2b::k2b_half)));
-    HIP_TRY(hipMemcpy(p->frag32, f32.data(), f32.size() * sizeof(k2b::k2b_half), hipMemcpyHostToDevice));
+    // upload; on any failure the partially built handle is released before the error is returned
+    auto upload_all = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = upload(&p->pa_image, pa.data(), pa.size())) != hipSuccess) return e;
+        if ((e = upload(&p->row_const, rc.data(), rc.size())) != hipSuccess) return e;
+        if ((e = upload(&p->nlw, nlw.data(), nlw.size())) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&p->frag32, f32.size() * sizeof(k2b::k2b_half))) != hipSuccess) return e;
+        return hipMemcpy(p->frag32, f32.data(), f32.size() * sizeof(k2b::k2b_half), hipMemcpyHostToDevice);
+    };
+    if (const hipError_t e = upload_all(); e != hipSuccess) {
+        k2b_prior_destroy(p);
+        return fail(K2B_ERR_HIP, "k2b_prior_create: upload failed: %s", hipGetErrorString(e));
+    }
     *out = p;
     return K2B_OK;
 }
