@@ -156,9 +156,12 @@ def main():
         out = native.fit_world(model.native, prior.native, cfg, list(range(22)), j3d, None, init.global_orient,
                                init.body_pose, init.betas, init.transl)
         e1.record()
+        # the parameter exchange is enqueued behind the fit and runs on RCCL's stream under the LBS launches
+        gathered, work = gather_fit_outputs(out, dist, async_op=True) if dist is not None else (None, None)
         joints, verts = model.native.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"])
         e2.record()
-        gathered = gather_fit_outputs(out, dist) if dist is not None else None
+        if work is not None:
+            work.wait()
         if record:
             fit_ms.append((e0, e1))
             lbs_ms.append((e1, e2))

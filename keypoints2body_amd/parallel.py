@@ -41,16 +41,21 @@ def unpack_outputs(packed: torch.Tensor, num_betas: int, pose_dim: int) -> Dict[
             "transl": tr.contiguous(), "loss": loss.reshape(-1).contiguous()}
 
 
-def gather_fit_outputs(out: Dict[str, torch.Tensor], dist=None, pad_to: Optional[int] = None) -> torch.Tensor:
+def gather_fit_outputs(out: Dict[str, torch.Tensor], dist=None, pad_to: Optional[int] = None, async_op: bool = False):
     """All-gather the packed outputs of every rank: returns (world * rows, P+1) on every rank.
 
     `dist` is the ``torch.distributed`` module (process group already initialised; backend
     ``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests).  `pad_to` = common row count
     when shards are uneven (rows beyond a rank's own frames are zero).
+
+    ``async_op=True`` returns ``(tensor, work)``: the collective is only enqueued (RCCL runs it on its
+    own stream, ordered after everything already launched on the current one), so the caller can launch
+    the LBS forward behind it and call ``work.wait()`` afterwards - the 340 B/frame exchange then travels
+    over xGMI while the vertex kernel runs.  ``work`` is ``None`` for a single rank.
     """
     packed = pack_outputs(out)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return packed
+        return (packed, None) if async_op else packed
     rows = packed.shape[0] if pad_to is None else pad_to
     if packed.shape[0] != rows:
         padded = packed.new_zeros((rows, packed.shape[1]))
@@ -58,8 +63,8 @@ def gather_fit_outputs(out: Dict[str, torch.Tensor], dist=None, pad_to: Optional
         packed = padded
     world = dist.get_world_size()
     gathered = packed.new_empty((world * rows, packed.shape[1]))
-    dist.all_gather_into_tensor(gathered, packed)
-    return gathered
+    work = dist.all_gather_into_tensor(gathered, packed, async_op=async_op)
+    return (gathered, work) if async_op else gathered
 
 
 def fit_frames_sharded(fit_fn: Callable[[slice], Dict[str, torch.Tensor]], num_frames: int, num_betas: int,

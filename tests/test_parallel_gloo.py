@@ -22,6 +22,13 @@ def test_shard_bounds_cover_every_frame_once():
             assert max(e - s for s, e in spans) == (T + G - 1) // G
 
 
+def test_single_rank_async_gather_returns_no_work():
+    out = {"global_orient": torch.randn(2, 3), "body_pose": torch.randn(2, 69), "betas": torch.randn(2, 10),
+           "transl": torch.randn(2, 3), "loss": torch.randn(2)}
+    packed, work = parallel.gather_fit_outputs(out, None, async_op=True)
+    assert work is None and torch.equal(packed, parallel.pack_outputs(out))
+
+
 def test_pack_unpack_roundtrip():
     out = {"global_orient": torch.randn(4, 3), "body_pose": torch.randn(4, 69), "betas": torch.randn(4, 10),
            "transl": torch.randn(4, 3), "loss": torch.randn(4)}
@@ -55,6 +62,13 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         res = parallel.fit_frames_sharded(_fit_block, 5, 10, 69, dist)     # 5 frames over 2 ranks: 3 + 2
+        # the asynchronous form used by bench.py (collective enqueued, other work launched, then waited for)
+        mine = _fit_block(slice(*parallel.shard_bounds(5, world, rank)))
+        gathered, work = parallel.gather_fit_outputs(mine, dist, pad_to=3, async_op=True)
+        assert work is not None
+        work.wait()
+        sync = parallel.gather_fit_outputs(mine, dist, pad_to=3)
+        assert torch.equal(gathered, sync)
         q.put((rank, {k: v.numpy() for k, v in res.items()}))
     finally:
         dist.destroy_process_group()
