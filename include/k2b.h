@@ -123,7 +123,7 @@ uint32_t k2b_fit_config_size(void);
  * independent frames: per iteration the SMPL joint forward (Rodrigues, kinematic chain,
  * J(beta)), `body_fitting_loss_3d` (core/losses.py:24-67) with `MaxMixturePrior`
  * (core/prior.py:182-195), the analytic backward and the Adam update, all iterations
- * fused in one launch (one frame per wavefront).
+ * fused in one launch (one or two wavefronts per frame, or two frames per wavefront, by batch size).
  *
  *   model_joint_index [K] HOST int32: model joint fitted to target k (the reference's
  *       smpl_index / target_model_indices, world_space.py:194-201); values must be
