@@ -214,19 +214,23 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
         *reinterpret_cast<half8*>(&wres[q][lane * 8]) = *reinterpret_cast<const half8*>(src);
     }
 
-    half8 stage[5];
-    auto load_pose = [&]() {
+    // Operand slices travel global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane x 16 B,
+    // which is exactly the lane-linear 1 KiB fragment): no staging registers and no LDS writes in the waves'
+    // instruction streams.  The loads of slice s + 1 are issued at the top of slice s into the other ring slot;
+    // the barrier at the end of the slice drains them (hipcc waits vmcnt(0) in front of __syncthreads).
+    auto load_pose = [&](int slot) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { stage[i] = *reinterpret_cast<const half8*>(psrc[i]); psrc[i] += pstride[i]; }
+        for (int i = 0; i < 5; ++i) {
+            __builtin_amdgcn_global_load_lds(psrc[i], &ring[slot][wave + 8 * i][0], 16, 0, 0);
+            psrc[i] += pstride[i];
+        }
     };
-    auto load_a = [&]() {
+    auto load_a = [&](int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { stage[i] = *reinterpret_cast<const half8*>(asrc[i]); asrc[i] += astride; }
-    };
-    auto commit = [&](int slot, int n) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (i < n) *reinterpret_cast<half8*>(&ring[slot][wave + 8 * i][lane * 8]) = stage[i];
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(asrc[i], &ring[slot][wave + 8 * i][0], 16, 0, 0);
+            asrc[i] += astride;
+        }
     };
     auto frag = [&](int slot, int q) -> half8 { return *reinterpret_cast<const half8*>(&ring[slot][q][lane * 8]); };
 
@@ -237,15 +241,14 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
         for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
     const int nslices = KS2 + 6;
-    load_pose();
-    commit(0, 5);
+    load_pose(0);
     __syncthreads();
 
     // ---- phase 1: v_posed * kPdScale = X . Pd for the three coordinates -----------------------------
     for (int s = 0; s < KS2; ++s) {
         const int slot = s & 1, nslot = slot ^ 1;
         const bool next_pose = s + 1 < KS2;
-        if (next_pose) load_pose(); else load_a();
+        if (next_pose) load_pose(nslot); else load_a(nslot);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the slice: its latency hides under the MFMAs
 #pragma unroll
         for (int ksl = 0; ksl < 2; ++ksl) {
@@ -260,7 +263,6 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        commit(nslot, next_pose ? 5 : 4);
         __syncthreads();
     }
     const float inv_scale = 1.0f / kPdScale;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
         for (int half = 0; half < 2; ++half) {
             const int s = KS2 + 2 * r + half, slot = s & 1, nslot = slot ^ 1;
             const bool more = s + 1 < nslices;
-            if (more) load_a();
+            if (more) load_a(nslot);
             __builtin_amdgcn_sched_barrier(0);
             floatx16 t2[2];
 #pragma unroll
@@ -310,7 +312,6 @@ __global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) commit(nslot, 4);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 16; ++i)
