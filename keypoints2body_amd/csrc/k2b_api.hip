@@ -328,7 +328,7 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
     if (M < 1 || M > k2b::kPriorMaxGauss)
         return fail(K2B_ERR_UNSUPPORTED, "k2b_prior_create: num_gaussians=%d, supported 1..%d", M, k2b::kPriorMaxGauss);
     for (int m = 0; m < M; ++m)
-        if (!(nll_weights[m] > 0.f)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_prior_create: nll_weights[%d] must be > 0", m);
+        if (!(nll_weights[m] >= 0.f)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_prior_create: nll_weights[%d] must be >= 0", m);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(K2B_ERR_NO_DEVICE, "k2b_prior_create: no HIP device visible (this engine has no CPU path)");
@@ -372,7 +372,7 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
             rc[(size_t)6 * 64 + l] = (float)kb;
             rc[(size_t)7 * 64 + l] = means[m * D + NC + s];
         }
-        nlw[m] = -logf(nll_weights[m]);
+        nlw[m] = -logf(nll_weights[m]);      // a weight that underflowed to 0 gives +inf, as torch.log does in the reference: never the arg-min
     }
     // the 64 x 64 core as MFMA A fragments (v_mfma_f32_16x16x32_f16: lane l holds row l & 15,
     // k = 8 (l >> 4) + j), two f16 terms per entry, scaled by a power of two per component so that the

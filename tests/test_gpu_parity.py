@@ -180,6 +180,66 @@ def test_sixteen_beta_model_matches_oracle(shape, monkeypatch):
     assert out["betas"].abs().max() > 1e-3          # the sixteen betas did move
 
 
+def test_ill_conditioned_prior_matches_oracle():
+    """The mixture prior runs on f16-split MFMA operands (two f16 terms per precision entry, power-of-two
+    scale per component).  A prior far harsher than the goldens' - precision entries above 1e4, condition
+    numbers above 1e4, components of very different scale, 5 components instead of 8 - must still reproduce the
+    CPU float32 arithmetic of the reference's formulation (oracle) within the parity budget."""
+    from keypoints2body_amd import native, synthetic
+    from keypoints2body_amd.native import NativePrior
+    from oracle.fit_torch import GMMPrior, fit_world_adam
+    rng = np.random.default_rng(17)
+    M = 5
+    means = 0.3 * rng.standard_normal((M, 69))
+    covars = np.zeros((M, 69, 69))
+    for m in range(M):
+        A = rng.standard_normal((69, 12)) * (0.02 * 1.4 ** m)
+        covars[m] = A @ A.T + np.diag(10.0 ** rng.uniform(-5.0, -1.0, 69))
+    prior_o = GMMPrior(means, covars, np.full(M, 1.0 / M))
+    P = prior_o.precisions.numpy()
+    assert np.abs(P).max() > 1e4 and np.linalg.cond(P[M - 1].astype(np.float64)) > 1e4 and (prior_o.nll_weights > 0).all()
+    prior_n = NativePrior(prior_o.means.numpy(), P, prior_o.nll_weights.numpy().reshape(-1))
+    B, iters = 4, 30
+    p = synthetic.make_poses(B, seed=9)
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32)
+    oracle = H.oracle_model()
+    with torch.no_grad():
+        j3d = oracle(global_orient=t(p.global_orient), body_pose=t(p.body_pose), betas=t(p.betas), transl=t(p.transl)).joints[:, :22]
+    go0, bp0, be0, tr0 = t(p.global_orient) * 0.7, t(p.body_pose) * 0.7, torch.zeros(B, 10), t(p.transl) + 0.01
+    ref = fit_world_adam(oracle, prior_o, go0, bp0, be0, tr0, j3d, num_iters=iters)
+    cfg = native.default_fit_config(); cfg.num_iters = iters
+    out = native.fit_world(H.native_model(), prior_n, cfg, list(range(22)), j3d.cuda().contiguous(), None,
+                           go0.cuda(), bp0.cuda(), be0.cuda(), tr0.cuda())
+    for key, want in (("global_orient", ref.global_orient), ("body_pose", ref.body_pose), ("betas", ref.betas), ("transl", ref.transl)):
+        err = (out[key].cpu() - want).abs().max().item()
+        assert err < PARAM_TOL, (key, err)
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), ref.loss.numpy(), rtol=2e-4)
+
+
+def test_underflowed_mixture_weight_is_never_selected():
+    """A mixture weight that underflows to 0 in float32 gives log(0) = -inf in the reference (prior.py:189):
+    that component can never be the arg-min.  Same here: with component 0's weight set to 0 the result equals
+    the fit with that component removed."""
+    from keypoints2body_amd import native
+    from keypoints2body_amd.native import NativePrior
+    g = H.gmm_fixture()
+    w = g["ref_nll_weights"].reshape(-1).copy()
+    w0 = w.copy(); w0[0] = 0.0
+    with_zero = NativePrior(g["ref_means"], g["ref_precisions"], w0)
+    without = NativePrior(g["ref_means"][1:], g["ref_precisions"][1:], w[1:])
+    d = H.load_case("amass_noisy_conf")
+    dev = lambda k: H.cuda(d[k])
+    cfg = native.default_fit_config(); cfg.num_iters = 20
+    run = lambda pr: native.fit_world(H.native_model(), pr, cfg, list(range(22)), dev("j3d"), H.cuda(d["conf"]),
+                                      dev("init_global_orient"), dev("init_body_pose"), dev("init_betas"), dev("init_transl"))
+    a, b = run(with_zero), run(without)
+    for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+        assert torch.isfinite(a[k]).all()
+        assert (a[k] - b[k]).abs().max() < 1e-6, k
+    with pytest.raises(ValueError):
+        NativePrior(g["ref_means"], g["ref_precisions"], -w)
+
+
 def test_fit_is_deterministic_and_frames_are_independent():
     d = H.load_case("amass_noisy_conf")
     a = H.native_fit(d)
