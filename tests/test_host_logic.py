@@ -41,6 +41,23 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.k2b_version() >> 16 == 1
 
 
+def test_header_is_plain_c_and_struct_size_matches(tmp_path):
+    """include/k2b.h is the drop-in boundary: it must compile as C99 and as C++ with nothing but the
+    standard headers, and sizeof(k2b_fit_config) seen by a C compiler must equal what the library and the
+    ctypes mirror use."""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include <stdio.h>\n#include "k2b.h"\nint main(void) { printf("%u\\n", (unsigned)sizeof(k2b_fit_config)); return 0; }\n')
+    inc = str(native.library_path().parents[2] / "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(tmp_path / "hdr")], check=True)
+    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)], check=True)
+    size = int(subprocess.run([str(tmp_path / "hdr")], check=True, capture_output=True, text=True).stdout)
+    import ctypes
+    assert size == ctypes.sizeof(native.FitConfigC) == native.load_library().k2b_fit_config_size()
+
+
 def test_default_fit_config_carries_reference_weights():
     c = native.default_fit_config()
     assert (c.num_iters, c.step_size, c.adam_beta1, c.adam_beta2, c.adam_eps) == (30, 1e-2, 0.9, 0.999, 1e-8)
