@@ -156,7 +156,7 @@ constexpr int kChunkGroups = 4;      // frame groups (128 frames each) per L2-re
 constexpr int kFragHalfs = 512;      // one fragment = 64 lanes x 8 halfs = 1 KiB
 constexpr int kSlotFrags = 40;       // fragments per ring slot
 
-__global__ __launch_bounds__(512, 2) void k2b_lbs_mfma_kernel(const SkinArgs a) {
+__global__ __launch_bounds__(512, 1) void k2b_lbs_mfma_kernel(const SkinArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 ring[2][kSlotFrags][kFragHalfs];   // 80 KiB
     __shared__ __attribute__((aligned(16))) _Float16 wres[8][kFragHalfs];               // 8 KiB (KA == 2)
     __shared__ __attribute__((aligned(16))) float parked[8][2][4][64][4];               // 64 KiB: x, y of each lane's 16 results
