@@ -49,6 +49,23 @@ def test_full_size_fit_is_deterministic_independent_and_converges(B):
     assert verts.shape == (B, 6890, 3) and torch.isfinite(verts).all()
 
 
+@pytest.mark.parametrize("B", [3, 1500, 2600])        # split (ragged), split-paired, paired
+def test_long_runs_stay_finite_and_keep_improving(B):
+    """1000 Adam iterations in one launch (ten times the benchmark's count): the in-kernel wave
+    synchronisation (barriers and the row waves' LDS counter) holds up, parameters stay finite and the joint
+    error does not get worse than after 100 iterations."""
+    j3d, tr0 = _problem(B)
+    short, long_ = _fit(j3d, tr0, iters=100), _fit(j3d, tr0, iters=1000)
+    model = H.native_model()
+    err = {}
+    for name, out in (("short", short), ("long", long_)):
+        for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+            assert torch.isfinite(out[k]).all(), (name, k)
+        joints, _ = model.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"], want_vertices=False)
+        err[name] = (joints[:, :22] - j3d).norm(dim=-1).mean().item()
+    assert err["long"] <= err["short"] * 1.05, err
+
+
 def test_translation_equivariance_of_the_fit():
     j3d, tr0 = _problem(512, seed=3)
     shift = torch.tensor([0.25, -1.5, 3.0], device="cuda")
