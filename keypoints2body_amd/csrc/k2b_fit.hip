@@ -442,6 +442,12 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const float ws2 = a.shape_w * a.shape_w;
     const float wpr2 = a.preserve_w * a.preserve_w;
     const float wt2 = a.transl_prior_w * a.transl_prior_w;
+    // set-B coefficients of the priors: gradient c_y y + 2 c_q (x - ref), loss share c_q (x - ref)^2
+    const float cyB = bodyB ? wpp2 : 0.f;
+    const float cqB = bodyB ? wpr2 : (betaB ? ws2 : (translB ? wt2 : 0.f));
+    float refB[FW];
+#pragma unroll
+    for (int h = 0; h < FW; ++h) refB[h] = bodyB ? pr1[h] : (translB ? tp1[h] : 0.f);
     const float om_b1 = a.one_minus_beta1;       // lerp weight float(1 - beta1), formed in double on host
     const float om_b2 = a.one_minus_beta2;       // float(1 - beta2) computed in double on host
 
@@ -570,9 +576,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             }
         }
         // ---- e. joint loss, its gradient, subtree force / torque sums ------------------------------
-        Vec3 gj = {0.f, 0.f, 0.f};
+        // (no branch on "this lane has a target": wconf = 0 there, so its loss and gradient vanish)
+        Vec3 gj;
         float part = 0.f;                  // per-lane partial of the joint loss
-        if (tk >= 0) {
+        {
             const float ex = pj.x + tr.x - tgt.x, ey = pj.y + tr.y - tgt.y, ez = pj.z + tr.z - tgt.z;
             const float x2 = ex * ex, y2 = ey * ey, z2 = ez * ez;
             const float dx = s2 + x2, dy = s2 + y2, dz = s2 + z2;
@@ -717,26 +724,15 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             yA += rimf[0 * 512] * t64.x + rimf[1 * 512] * t64.y + rimf[2 * 512] * t64.z + rimf[3 * 512] * t64.w + rimf[4 * 512] * t68;
             yBs = bperm((8 * mstar + (lane < NR ? lane : 0)) * 4, yB[h]);   // rows 64 + lane for lanes < 5
         }
+        // Branch-free: every lane evaluates  c_y y + 2 c_q (x - ref)  with its own coefficients (set A: mixture
+        // + preserve; set B: the same for body_pose[64..68], shape prior for betas, transl prior for transl,
+        // zeros elsewhere), and the angle prior's exp() runs with sign 0 (-> 1, times 0) outside its four lanes.
+        const float dA = x0[h] - pr0[h], dB = x1[h] - refB[h];
+        const float eA = __expf(x0[h] * angA);
+        const float ga = wpp2 * yA + 2.f * wpr2 * dA + (wa2 * 2.f * angA) * (eA * eA);
+        const float gb = cyB * yBs + 2.f * cqB * dB;
         float part = 0.f;                  // per-lane partial of the prior losses
-        float ga = wpp2 * yA + 2.f * wpr2 * (x0[h] - pr0[h]), gb = 0.f;
-        if (angA != 0.f) {
-            const float e = __expf(x0[h] * angA);
-            ga += wa2 * 2.f * angA * e * e;
-            if (last) part += wa2 * e * e;
-        }
-        if (last) part += wpr2 * (x0[h] - pr0[h]) * (x0[h] - pr0[h]);
-        if (bodyB) {
-            gb = wpp2 * yBs + 2.f * wpr2 * (x1[h] - pr1[h]);
-            if (last) part += wpr2 * (x1[h] - pr1[h]) * (x1[h] - pr1[h]);
-        }
-        if (betaB) {
-            gb = 2.f * ws2 * x1[h];
-            if (last) part += ws2 * x1[h] * x1[h];
-        }
-        if (translB) {
-            gb = 2.f * wt2 * (x1[h] - tp1[h]);
-            if (last) part += wt2 * (x1[h] - tp1[h]) * (x1[h] - tp1[h]);
-        }
+        if (last) part = wpr2 * dA * dA + (angA != 0.f ? wa2 * eA * eA : 0.f) + cqB * dB * dB;
         gp0[h] = ga; gp1[h] = gb; lossp[h] = part; bestv[h] = best;
         }  // frames of this wave
     };
