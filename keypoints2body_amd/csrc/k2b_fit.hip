@@ -690,11 +690,13 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             y.z = yacc[t][2] * inv_scale - c4.z;
             y.w = yacc[t][3] * inv_scale - c4.w;
             qp += (th4.x - mu4.x) * y.x + (th4.y - mu4.y) * y.y + (th4.z - mu4.z) * y.z + (th4.w - mu4.w) * y.w;
-            if (cn < F) *reinterpret_cast<float4*>(yx + cn * YX_STRIDE + comp * NC + 16 * t + 4 * cg) = y;
+            // (columns beyond the workgroup's frames repeat the last slot's theta, so they hold the same values:
+            //  every lane stores, no predicate)
+            *reinterpret_cast<float4*>(yx + cslot * YX_STRIDE + comp * NC + 16 * t + 4 * cg) = y;
         }
         qp = pair_sum32(qp);
-        qp = pair_sum16(qp);                             // summed over the four row groups g
-        if (cg == 0 && cn < F) qx[cn * MG + comp] = qp;
+        qp = pair_sum16(qp);                             // summed over the four row groups g: all four hold the total
+        qx[cslot * MG + comp] = qp;
     };
 
     // ---- row role, part 1 (needs y and q of every component, not the tree): arg-min component, its y in
@@ -741,20 +743,22 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
 #pragma unroll
         for (int h = 0; h < FW; ++h) {
         const float* gs_r = slots + (slot0 + h) * SLOT + XS;
-        g0[h] = gs_r[offA] + gp0[h];
-        g1[h] = actB ? gs_r[offB] + gp1[h] : 0.f;
+        // (a parameter that is not optimised gets gradient 0: Adam then leaves it and its state untouched, so the
+        //  update below needs no branch)
+        g0[h] = optA ? gs_r[offA] + gp0[h] : 0.f;
+        g1[h] = optB ? gs_r[offB] + gp1[h] : 0.f;
         if (last) loss_total[h] = wave_sum_fast(lossp[h]) + wpp2 * bestv[h] + gs_r[XS - 1];
 
         // torch.optim.Adam, single-tensor path
         const float2 co = a.adam_coef[it];     // {lr / (1 - b1^t), sqrt(1 - b2^t)}
         const float inv_bc2 = fast_rcp(co.y);
-        if (optA) {
+        {
             m0[h] = m0[h] + om_b1 * (g0[h] - m0[h]);
             v0[h] = v0[h] * a.beta2 + om_b2 * g0[h] * g0[h];
             const float denom = fast_sqrt(v0[h]) * inv_bc2 + a.eps;
             x0[h] = x0[h] - co.x * (m0[h] * fast_rcp(denom));
         }
-        if (optB) {
+        {
             m1[h] = m1[h] + om_b1 * (g1[h] - m1[h]);
             v1[h] = v1[h] * a.beta2 + om_b2 * g1[h] * g1[h];
             const float denom = fast_sqrt(v1[h]) * inv_bc2 + a.eps;
@@ -869,8 +873,8 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         if (lane == 0 && a.loss_out) a.loss_out[fr] = loss_total[h];
         if (a.grad_out) {
             const int P = 3 + D + NB + 3;
-            a.grad_out[(size_t)fr * P + pA] = optA ? g0[h] : 0.f;
-            if (actB) a.grad_out[(size_t)fr * P + pB] = optB ? g1[h] : 0.f;
+            a.grad_out[(size_t)fr * P + pA] = g0[h];
+            if (actB) a.grad_out[(size_t)fr * P + pB] = g1[h];
         }
     }
 }
