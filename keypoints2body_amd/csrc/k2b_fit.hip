@@ -342,6 +342,11 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const float cB = a.row_const[5 * 64 + lane];    // (P mu)[64 + gs]
     const float kB = a.row_const[6 * 64 + lane];    // (P_BA mu_A)[gs]
     const float muB = a.row_const[7 * 64 + lane];   // mu[64 + gs]
+    // one-hot of gs over the five rim rows: "element gs of five" as a sum of products - hipcc turns the
+    // equivalent chain of ?: into lane-divergent branches
+    float mk[NR];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) mk[c] = gs == c ? 1.f : 0.f;
     // float4 index of P_m[64 + c][lane] (= P_m[lane][64 + c]) in the rim image, without the m and c terms
     const int rimcol = (((lane >> 2) & 1) * 64 + (lane >> 3)) * 4 + (lane & 3);
 
@@ -527,8 +532,8 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 }
 #pragma unroll
                 for (int c = 0; c < NR; ++c) w[c] = group8_sum(w[c]);
-                const float wm = gs == 0 ? w[0] : (gs == 1 ? w[1] : (gs == 2 ? w[2] : (gs == 3 ? w[3] : w[4])));
-                const float tB = gs == 0 ? t64.x : (gs == 1 ? t64.y : (gs == 2 ? t64.z : (gs == 3 ? t64.w : t68)));
+                const float wm = mk[0] * w[0] + mk[1] * w[1] + mk[2] * w[2] + mk[3] * w[3] + mk[4] * w[4];        // w[gs]
+                const float tB = mk[0] * t64.x + mk[1] * t64.y + mk[2] * t64.z + mk[3] * t64.w + mk[4] * t68;   // theta_B[gs]
                 const float vB = pbb[0] * t64.x + pbb[1] * t64.y + pbb[2] * t64.z + pbb[3] * t64.w + pbb[4] * t68;
                 const float y = wm + vB - cB;
                 const float term = tB * (wm - kB) + (tB - muB) * y;
