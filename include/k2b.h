@@ -158,6 +158,30 @@ int k2b_lbs(const k2b_model *model, int32_t num_frames, const float *global_orie
             float *joints_out, float *vertices_out, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * Vertex-selected joints in the loss (slow path).  `target_model_indices` of the reference
+ * (world_space.py:198-201) may name smplx's "extra" joints, which are single mesh vertices
+ * (index J + e, e < E).  The fused kernel fits kinematic joints only; for the others the
+ * host runs the Adam loop itself with three launches per iteration: k2b_fit_world in
+ * evaluate-only mode (num_iters = 1, step_size = 0, grad_out) for the kinematic targets and
+ * the priors, k2b_vertex_term for the vertex targets, k2b_adam_step for the update.
+ *
+ * k2b_vertex_term: loss [B] and gradient [B][3 + 3(J-1) + NB + 3] (layout of grad_out above)
+ *   of  joint_loss_weight^2 conf_e^2 sum_xyz gmof(vertex_e + transl - target_e)  over the E_sel
+ *   selected extra joints; extra_index HOST int32 [E_sel] in [0, E); targets dev [B][E_sel][3];
+ *   conf dev [E_sel] or NULL.  At most 32 selected joints per call.
+ * k2b_adam_step: torch.optim.Adam single-tensor update of n floats for step t = 1, 2, ...
+ *   (bias corrections formed in double like the fused kernel's table); m, v are the caller's
+ *   state buffers (zero before the first step).
+ * ------------------------------------------------------------------------------- */
+int k2b_vertex_term(const k2b_model *model, int32_t num_frames, int32_t num_selected,
+                    const int32_t *extra_index, const float *targets, const float *conf,
+                    float sigma, float joint_loss_weight, const float *global_orient,
+                    const float *body_pose, const float *betas, const float *transl,
+                    float *loss_out, float *grad_out, void *stream);
+int k2b_adam_step(int64_t n, float *params, const float *grad, float *m, float *v, int32_t step,
+                  double step_size, double beta1, double beta2, double eps, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * k2b_angular_error_deg — the evaluation metric behind MPJAE.  Replaces
  * `compute_angular_error_deg` (reference cli/eval.py:131-140, with `rotvec_to_rotmat`
  * :88-128) for n pairs of axis-angle rotations:

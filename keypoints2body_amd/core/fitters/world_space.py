@@ -18,8 +18,10 @@ Differences, all deliberate and documented in DESIGN.md:
 
 * hand / face parameters of ``SMPLHData`` / ``SMPLXData`` inputs are carried through
   unchanged (the fused kernel fits the 24-joint SMPL tree);
-* vertex-selected joints (model joint index >= 24) cannot be fitted yet
-  (``NotImplementedError``);
+* vertex-selected joints (model joint index >= 24: smplx's "extra" joints, single mesh vertices) take a slow
+  path: the fused kernel fits kinematic joints only, so the Adam loop then runs on the host with three
+  launches per iteration (``k2b_fit_world`` evaluate-only for the kinematic targets and the priors,
+  ``k2b_vertex_term`` for the vertex targets, ``k2b_adam_step``); roughly ten times the fused path's time;
 * ``fit_batch`` fits B independent frames in one launch with optional per-frame
   confidences; ``fit_frame`` keeps the reference's behaviour of using row 0 of a 2-D
   confidence tensor (``world_space.py:163-164``).
@@ -132,13 +134,64 @@ class WorldSpaceFitter:
 
         cfg = self._config(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
                            per_frame_conf and conf is not None and conf.dim() == 2)
-        if self.use_lbfgs:
+        if any(i >= J for i in model_idx):
+            if self.use_lbfgs:
+                raise NotImplementedError("vertex-selected joints (model index >= %d) with use_lbfgs=True: only the Adam "
+                                          "branch has the vertex term; set use_lbfgs=False" % J)
+            out = self._fit_with_vertex_joints(cfg, model_idx, tgt, conf, go, bp, be, tr)
+        elif self.use_lbfgs:
             out = self._fit_lbfgs(cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas)
         else:
             out = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, go, bp, be, tr)
         joints, verts = self.smpl.native.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"],
                                              want_vertices=want_vertices)
         return out, joints, verts, out["loss"]
+
+    def _fit_with_vertex_joints(self, cfg, model_idx, tgt, conf, go, bp, be, tr):
+        """Adam branch with vertex-selected joints among the targets (``world_space.py:198-201`` with indices
+        >= 24): the host drives the iterations.  Per iteration: loss and gradient of the kinematic targets and of
+        every prior from an evaluate-only launch of the fused kernel, loss and gradient of the vertex targets from
+        ``k2b_vertex_term``, then one ``k2b_adam_step`` over the packed parameters (the same arithmetic as the fused
+        kernel's update).  Returns the same dict as ``native.fit_world``; ``loss`` is the loss of the last iteration
+        before its step (``world_space.py:256``)."""
+        J = self.smpl.num_joints
+        if conf is not None and conf.dim() == 2:
+            raise NotImplementedError("per-frame confidences with vertex-selected joints")
+        kin = [k for k, i in enumerate(model_idx) if i < J]
+        vtx = [k for k, i in enumerate(model_idx) if i >= J]
+        if not kin:
+            raise NotImplementedError("at least one kinematic joint (model index < %d) must be among the targets" % J)
+        num_extra = self.smpl.native.num_extra
+        if any(model_idx[k] - J >= num_extra for k in vtx):
+            raise ValueError(f"target_model_indices must be < {J + num_extra}")
+        kin_idx, vtx_idx = [model_idx[k] for k in kin], [model_idx[k] - J for k in vtx]
+        tgt_k, tgt_v = tgt[:, kin].contiguous(), tgt[:, vtx].contiguous()
+        conf_k = None if conf is None else conf[kin].contiguous()
+        conf_v = None if conf is None else conf[vtx].contiguous()
+        num_iters, lr = int(cfg.num_iters), float(cfg.step_size)
+        cfg.num_iters, cfg.step_size = 1, 0.0                     # evaluate-only launches of the fused kernel
+        B, D, NB = go.shape[0], bp.shape[1], be.shape[1]
+        cols = (slice(0, 3), slice(3, 3 + D), slice(3 + D, 3 + D + NB), slice(3 + D + NB, 3 + D + NB + 3))
+        params = torch.cat([go, bp, be, tr], dim=1).contiguous()
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        preserve = bp.clone()
+        mask = int(cfg.optimize_mask) & (~4 if cfg.freeze_betas else ~0)
+        loss = None
+        for step in range(1, num_iters + 1):
+            p = [params[:, c].contiguous() for c in cols]
+            ev = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, kin_idx, tgt_k, conf_k, p[0], p[1], p[2], p[3],
+                                  preserve_pose=preserve, want_grad=True)
+            loss_v, grad_v = native.vertex_term(self.smpl.native, vtx_idx, tgt_v, conf_v, float(cfg.sigma),
+                                                float(cfg.joint_loss_weight), p[0], p[1], p[2], p[3])
+            for bit, c in zip((1, 2, 4, 8), cols):                # parameters outside the optimiser get no gradient
+                if not (mask & bit):
+                    grad_v[:, c] = 0.0
+            grad = (ev["grad"] + grad_v).contiguous()
+            loss = ev["loss"] + loss_v
+            native.adam_step(params, grad, m, v, step, lr, float(cfg.adam_beta1), float(cfg.adam_beta2), float(cfg.adam_eps))
+        out = {k: params[:, c].contiguous() for k, c in zip(("global_orient", "body_pose", "betas", "transl"), cols)}
+        out["loss"] = loss if loss is not None else torch.zeros(B, device=params.device)
+        return out
 
     def _fit_lbfgs(self, cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas):
         """LBFGS branch (world_space.py:231-247): ``torch.optim.LBFGS(params, max_iter=num_iters,

@@ -69,6 +69,7 @@ struct k2b_model {
     std::string fit_why;
     float *dt = nullptr, *dd = nullptr;
     int* tree = nullptr;
+    int* sel_ws = nullptr;                                   // device copy of the selected extra-joint indices (vertex term)
     std::vector<int> depth;                                  // depth of every joint (root 0)
     // LBS B operands (f16 hi/lo, MFMA fragment order) for the whole mesh and for the E extra-joint vertices
     struct VertexSet {
@@ -299,6 +300,7 @@ void k2b_model_destroy(k2b_model* m) {
     if (m->parents) (void)hipFree(m->parents);
     if (m->extra_ids) (void)hipFree(m->extra_ids);
     if (m->tree) (void)hipFree(m->tree);
+    if (m->sel_ws) (void)hipFree(m->sel_ws);
     for (auto& kv : m->adam_tables) (void)hipFree(kv.second);
     delete m;
 }
@@ -576,6 +578,49 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     } else if (joints_out && m->E > 0) {
         HIP_TRY(skin(m->extra, joints_out, m->J + m->E, m->J));
     }
+    return K2B_OK;
+}
+
+int k2b_vertex_term(const k2b_model* model_c, int32_t B, int32_t E_sel, const int32_t* extra_index, const float* targets,
+                    const float* conf, float sigma, float joint_loss_weight, const float* go, const float* bp, const float* be,
+                    const float* tr, float* loss_out, float* grad_out, void* stream_v) {
+    k2b_model* m = const_cast<k2b_model*>(model_c);
+    if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: model is NULL");
+    if (B < 0 || E_sel < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: negative size");
+    if (B == 0 || E_sel == 0) return K2B_OK;
+    if (m->J != k2b::kFitJoints) return fail(K2B_ERR_UNSUPPORTED, "k2b_vertex_term: built for the %d-joint SMPL tree, model has %d", k2b::kFitJoints, m->J);
+    if (E_sel > 32) return fail(K2B_ERR_UNSUPPORTED, "k2b_vertex_term: %d vertex-selected joints, at most 32 per call", E_sel);
+    if (!extra_index || !targets || !go || !bp || !be || !tr || !loss_out || !grad_out)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: NULL buffer");
+    for (int e = 0; e < E_sel; ++e)
+        if (extra_index[e] < 0 || extra_index[e] >= m->E)
+            return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: extra_index[%d]=%d outside [0,%d)", e, extra_index[e], m->E);
+    hipStream_t stream = (hipStream_t)stream_v;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (!m->sel_ws) HIP_TRY(hipMalloc((void**)&m->sel_ws, 32 * sizeof(int)));
+    }
+    HIP_TRY(hipMemcpyAsync(m->sel_ws, extra_index, (size_t)E_sel * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));     // extra_index is the caller's host memory
+    k2b::VertexTermArgs a{};
+    a.v_template = m->v_template; a.shapedirs = m->shapedirs; a.posedirs = m->posedirs; a.lbs_weights = m->lbs_weights;
+    a.j_template = m->j_template; a.j_dirs = m->j_dirs; a.parents = m->parents; a.extra_ids = m->extra_ids;
+    a.num_vertices = m->V; a.num_betas = m->NB;
+    a.num_frames = B; a.num_sel = E_sel; a.sel = m->sel_ws; a.targets = targets; a.conf = conf;
+    a.sigma = sigma; a.joint_w = joint_loss_weight;
+    a.go = go; a.bp = bp; a.be = be; a.tr = tr; a.loss_out = loss_out; a.grad_out = grad_out;
+    HIP_TRY(k2b::launch_vertex_term(a, stream));
+    return K2B_OK;
+}
+
+int k2b_adam_step(int64_t n, float* params, const float* grad, float* mbuf, float* vbuf, int32_t step, double step_size,
+                  double beta1, double beta2, double eps, void* stream_v) {
+    if (n < 0 || step < 1) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_adam_step: n=%lld step=%d", (long long)n, step);
+    if (n == 0) return K2B_OK;
+    if (!params || !grad || !mbuf || !vbuf) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_adam_step: NULL buffer");
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    HIP_TRY(k2b::launch_adam(params, grad, mbuf, vbuf, (long long)n, (float)(step_size / bc1), (float)std::sqrt(bc2),
+                             (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (hipStream_t)stream_v));
     return K2B_OK;
 }
 

@@ -111,6 +111,25 @@ hipError_t launch_gather_joints(const float* verts, const int* ids, float* joint
 hipError_t launch_jreg_contract(const float* j_regressor, const float* rhs, float* out, int J, int V, int N,
                                 float* partial_ws, int num_splits, hipStream_t stream);
 
+// Joint-loss term of vertex-selected joints and its gradient (slow path, k2b_vertex.hip).
+struct VertexTermArgs {
+    // model (device): smplx tensors as uploaded by k2b_model_create
+    const float *v_template, *shapedirs, *posedirs, *lbs_weights, *j_template, *j_dirs;
+    const int *parents, *extra_ids;
+    int num_vertices, num_betas;
+    // call
+    int num_frames, num_sel;
+    const int* sel;             // dev [num_sel]: index into extra_ids of every fitted vertex joint
+    const float* targets;       // dev [B][num_sel][3]
+    const float* conf;          // dev [num_sel] or null
+    float sigma, joint_w;
+    const float *go, *bp, *be, *tr;
+    float *loss_out, *grad_out; // dev [B], [B][3 + 69 + NB + 3]
+};
+hipError_t launch_vertex_term(const VertexTermArgs& a, hipStream_t stream);
+hipError_t launch_adam(float* x, const float* g, float* m, float* v, long long n, float lr_over_bc1, float sqrt_bc2,
+                       float one_minus_beta1, float beta2, float one_minus_beta2, float eps, hipStream_t stream);
+
 // Geodesic angle (degrees) between n pairs of axis-angle rotations (evaluation metric, k2b_metrics.hip).
 hipError_t launch_angular_error(const float* pred, const float* gt, float* out, long long n, hipStream_t stream);
 

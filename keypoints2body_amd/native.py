@@ -26,7 +26,7 @@ K2B_ERR_NO_DEVICE = -4
 EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
     "k2b_model_joint_basis", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
-    "k2b_fit_world", "k2b_lbs", "k2b_angular_error_deg",
+    "k2b_fit_world", "k2b_lbs", "k2b_vertex_term", "k2b_adam_step", "k2b_angular_error_deg",
 )
 
 
@@ -95,6 +95,10 @@ def load_library():
     lib.k2b_fit_world.argtypes = [vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 14 + [vp]
     lib.k2b_lbs.restype = C.c_int
     lib.k2b_lbs.argtypes = [vp, C.c_int32] + [fp] * 6 + [vp]
+    lib.k2b_vertex_term.restype = C.c_int
+    lib.k2b_vertex_term.argtypes = [vp, C.c_int32, C.c_int32, ip, fp, fp, C.c_float, C.c_float] + [fp] * 6 + [vp]
+    lib.k2b_adam_step.restype = C.c_int
+    lib.k2b_adam_step.argtypes = [C.c_int64, fp, fp, fp, fp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     lib.k2b_angular_error_deg.restype = C.c_int
     lib.k2b_angular_error_deg.argtypes = [C.c_int64, fp, fp, fp, vp]
     _lib = lib
@@ -308,3 +312,41 @@ def angular_error_deg(pred_rotvec: torch.Tensor, gt_rotvec: torch.Tensor) -> tor
         _check(load_library().k2b_angular_error_deg(n, _dev(pred_rotvec, "pred_rotvec", dev), _dev(gt_rotvec, "gt_rotvec", dev),
                                                     C.c_void_p(out.data_ptr()) if n else None, stream), "k2b_angular_error_deg")
     return out
+
+
+def vertex_term(model: NativeModel, extra_index: Sequence[int], targets: torch.Tensor, conf: Optional[torch.Tensor],
+                sigma: float, joint_loss_weight: float, global_orient: torch.Tensor, body_pose: torch.Tensor,
+                betas: torch.Tensor, transl: torch.Tensor):
+    """Loss (B,) and gradient (B, P) of the joint-loss term of vertex-selected joints (``k2b_vertex_term``)."""
+    dev = model.device
+    B, E = targets.shape[0], targets.shape[1]
+    D = 3 * (model.num_joints - 1)
+    idx = _host_i32(np.asarray(list(extra_index)))
+    if idx.shape != (E,):
+        raise ValueError(f"extra_index has {idx.shape[0]} entries for {E} targets")
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    grad = torch.empty((B, 3 + D + model.num_betas + 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _check(load_library().k2b_vertex_term(
+            model.handle, B, E, _np_ptr(idx), _dev(targets, "targets", dev, (B, E, 3)), _dev(conf, "conf", dev, (E,)),
+            float(sigma), float(joint_loss_weight), _dev(global_orient, "global_orient", dev, (B, 3)),
+            _dev(body_pose, "body_pose", dev, (B, D)), _dev(betas, "betas", dev, (B, model.num_betas)),
+            _dev(transl, "transl", dev, (B, 3)), C.c_void_p(loss.data_ptr()), C.c_void_p(grad.data_ptr()), stream),
+            "k2b_vertex_term")
+    return loss, grad
+
+
+def adam_step(params: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, step_size: float,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """In-place ``torch.optim.Adam`` single-tensor step ``step`` (1-based) on a flat float32 block (``k2b_adam_step``)."""
+    dev = require_device(params.device)
+    n = params.numel()
+    for name, t in (("grad", grad), ("m", m), ("v", v)):
+        if t.numel() != n:
+            raise ValueError(f"{name} has {t.numel()} elements, params {n}")
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _check(load_library().k2b_adam_step(n, _dev(params, "params", dev), _dev(grad, "grad", dev), _dev(m, "m", dev),
+                                            _dev(v, "v", dev), int(step), float(step_size), float(beta1), float(beta2),
+                                            float(eps), stream), "k2b_adam_step")

@@ -157,6 +157,42 @@ def test_camera_space_fitter_matches_reference_golden(assets, case):
         assert np.abs(r1.params.transl.cpu().numpy() - d["out_transl"][:1]).max() < tol
 
 
+def test_vertex_selected_joints_match_reference_golden(assets):
+    """GENERIC targets that include smplx's vertex-selected joints (model indices 24, 25, 30, 37, 44 beside the 22
+    kinematic ones): the reference's fit differentiates through blend shapes and LBS of those vertices.  Here the
+    slow path of ``WorldSpaceFitter`` (evaluate-only fused kernel + ``k2b_vertex_term`` + ``k2b_adam_step`` per
+    iteration) must reproduce the reference's parameters at every recorded iteration, every iteration's loss and
+    the final joints, at the same 1e-4 as the fused path."""
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    model, prior = assets
+    d = dict(np.load(H.GOLDEN / "world_fit_generic_vertex_joints.npz"))
+    idx = torch.tensor(d["target_model_indices"])
+    assert int((idx >= 24).sum()) == 5
+    t = lambda k: torch.tensor(d[k])
+    init = k2b.SMPLData(betas=t("init_betas"), global_orient=t("init_global_orient"), body_pose=t("init_body_pose"),
+                        transl=t("init_transl"))
+    worst = 0.0
+    for ti, it in enumerate(list(d["trace_iters"]) + [int(d["num_iters"])]):
+        fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=int(it), num_iters_followup=int(it), use_lbfgs=False,
+                                  joints_category="GENERIC", pose_prior=prior)
+        out, joints, verts, loss = fitter.fit_batch(init, t("j3d"), conf_3d=t("conf"), seq_ind=0, target_model_indices=idx)
+        final = ti == len(d["trace_iters"])
+        for key in ("global_orient", "body_pose", "betas", "transl"):
+            want = d["out_" + key] if final else d["trace_" + key][ti]
+            err = np.abs(out[key].cpu().numpy() - want).max()
+            worst = max(worst, err)
+            assert err < TOL, (int(it), key, err)
+        np.testing.assert_allclose(loss.cpu().numpy(), d["iter_losses"][:, int(it) - 1], rtol=2e-5)
+    assert np.abs(joints.cpu().numpy() - d["out_joints"]).max() < TOL
+    vs = verts[:, torch.as_tensor(d["sampled_vertex_ids"]).cuda()].cpu().numpy()
+    assert np.abs(vs - d["out_verts_sampled"]).max() < TOL
+    print(f"vertex-selected joints: worst parameter deviation over the trace = {worst:.2e}")
+    # the LBFGS branch has no vertex term
+    lb = WorldSpaceFitter(model, use_lbfgs=True, joints_category="GENERIC", pose_prior=prior)
+    with pytest.raises(NotImplementedError):
+        lb.fit_batch(init, t("j3d"), conf_3d=t("conf"), seq_ind=0, target_model_indices=idx)
+
+
 @pytest.mark.parametrize("case", ["first", "followup_frozen"])
 def test_lbfgs_camera_fit_matches_reference_golden(assets, case):
     """LBFGS branches of the camera-space fitter (both stages).  Same statistical gate as the world LBFGS

@@ -252,6 +252,36 @@ def test_fit_is_deterministic_and_frames_are_independent():
 
 
 def test_vertex_joint_targets_are_rejected_loudly():
+    """k2b_fit_world itself fits kinematic joints only and says so; the fitter routes such targets through
+    k2b_vertex_term (tests/test_gpu_api.py::test_vertex_selected_joints_match_reference_golden)."""
     d = H.load_case("generic_vertex_joints")
     with pytest.raises(NotImplementedError):
         H.native_fit(d)
+
+
+def test_vertex_joint_term_gradient_matches_autograd():
+    """k2b_vertex_term: loss and analytic gradient of the joint loss on vertex-selected joints (blend shapes, LBS
+    and chain differentiated by hand) against torch autograd through the oracle's SMPL forward."""
+    from keypoints2body_amd import native, synthetic
+    from oracle.fit_torch import gmof
+    B = 3
+    sel = [0, 1, 6, 13, 20]
+    p = synthetic.make_poses(B, seed=21)
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32)
+    go, bp, be, tr = (t(p.global_orient).requires_grad_(), t(p.body_pose).requires_grad_(), t(p.betas).requires_grad_(),
+                      t(p.transl).requires_grad_())
+    oracle = H.oracle_model()
+    joints = oracle(global_orient=go, body_pose=bp, betas=be, transl=tr).joints
+    gen = torch.Generator().manual_seed(3)
+    tgt = (joints[:, [24 + e for e in sel]].detach() + 0.05 * torch.randn(B, len(sel), 3, generator=gen))
+    conf = torch.tensor([1.0, 0.7, 1.5, 1.0, 0.9])
+    lf = ((600.0 ** 2) * (conf ** 2).view(1, -1, 1) * gmof(joints[:, [24 + e for e in sel]] - tgt, 100.0)).sum(dim=(1, 2))
+    lf.sum().backward()
+    g_ref = torch.cat([go.grad, bp.grad, be.grad, tr.grad], dim=1).numpy()
+    loss, grad = native.vertex_term(H.native_model(), sel, tgt.cuda().contiguous(), conf.cuda(), 100.0, 600.0,
+                                    go.detach().cuda(), bp.detach().cuda(), be.detach().cuda(), tr.detach().cuda())
+    np.testing.assert_allclose(loss.cpu().numpy(), lf.detach().numpy(), rtol=2e-5)
+    g = grad.cpu().numpy()
+    for name, sl in (("global_orient", slice(0, 3)), ("body_pose", slice(3, 72)), ("betas", slice(72, 82)), ("transl", slice(82, 85))):
+        scale = np.abs(g_ref[:, sl]).max()
+        assert np.abs(g[:, sl] - g_ref[:, sl]).max() / scale < 5e-5, name
