@@ -21,7 +21,8 @@ Differences, all deliberate and documented in DESIGN.md:
 * vertex-selected joints (model joint index >= 24: smplx's "extra" joints, single mesh vertices) take a slow
   path: the fused kernel fits kinematic joints only, so the Adam loop then runs on the host with three
   launches per iteration (``k2b_fit_world`` evaluate-only for the kinematic targets and the priors,
-  ``k2b_vertex_term`` for the vertex targets, ``k2b_adam_step``); roughly ten times the fused path's time;
+  ``k2b_vertex_term`` for the vertex targets, ``k2b_adam_step``); roughly ten times the fused path's time
+  (the LBFGS branch adds the vertex term to its closure the same way);
 * ``fit_batch`` fits B independent frames in one launch with optional per-frame
   confidences; ``fit_frame`` keeps the reference's behaviour of using row 0 of a 2-D
   confidence tensor (``world_space.py:163-164``).
@@ -134,10 +135,7 @@ class WorldSpaceFitter:
 
         cfg = self._config(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
                            per_frame_conf and conf is not None and conf.dim() == 2)
-        if any(i >= J for i in model_idx):
-            if self.use_lbfgs:
-                raise NotImplementedError("vertex-selected joints (model index >= %d) with use_lbfgs=True: only the Adam "
-                                          "branch has the vertex term; set use_lbfgs=False" % J)
+        if any(i >= J for i in model_idx) and not self.use_lbfgs:
             out = self._fit_with_vertex_joints(cfg, model_idx, tgt, conf, go, bp, be, tr)
         elif self.use_lbfgs:
             out = self._fit_lbfgs(cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas)
@@ -147,13 +145,8 @@ class WorldSpaceFitter:
                                              want_vertices=want_vertices)
         return out, joints, verts, out["loss"]
 
-    def _fit_with_vertex_joints(self, cfg, model_idx, tgt, conf, go, bp, be, tr):
-        """Adam branch with vertex-selected joints among the targets (``world_space.py:198-201`` with indices
-        >= 24): the host drives the iterations.  Per iteration: loss and gradient of the kinematic targets and of
-        every prior from an evaluate-only launch of the fused kernel, loss and gradient of the vertex targets from
-        ``k2b_vertex_term``, then one ``k2b_adam_step`` over the packed parameters (the same arithmetic as the fused
-        kernel's update).  Returns the same dict as ``native.fit_world``; ``loss`` is the loss of the last iteration
-        before its step (``world_space.py:256``)."""
+    def _split_targets(self, model_idx, tgt, conf):
+        """Kinematic targets (fused kernel) and vertex-selected ones (``k2b_vertex_term``) of a target list."""
         J = self.smpl.num_joints
         if conf is not None and conf.dim() == 2:
             raise NotImplementedError("per-frame confidences with vertex-selected joints")
@@ -164,10 +157,18 @@ class WorldSpaceFitter:
         num_extra = self.smpl.native.num_extra
         if any(model_idx[k] - J >= num_extra for k in vtx):
             raise ValueError(f"target_model_indices must be < {J + num_extra}")
-        kin_idx, vtx_idx = [model_idx[k] for k in kin], [model_idx[k] - J for k in vtx]
-        tgt_k, tgt_v = tgt[:, kin].contiguous(), tgt[:, vtx].contiguous()
-        conf_k = None if conf is None else conf[kin].contiguous()
-        conf_v = None if conf is None else conf[vtx].contiguous()
+        pick = lambda rows: None if conf is None else conf[rows].contiguous()
+        return ([model_idx[k] for k in kin], tgt[:, kin].contiguous(), pick(kin),
+                [model_idx[k] - J for k in vtx], tgt[:, vtx].contiguous(), pick(vtx))
+
+    def _fit_with_vertex_joints(self, cfg, model_idx, tgt, conf, go, bp, be, tr):
+        """Adam branch with vertex-selected joints among the targets (``world_space.py:198-201`` with indices
+        >= 24): the host drives the iterations.  Per iteration: loss and gradient of the kinematic targets and of
+        every prior from an evaluate-only launch of the fused kernel, loss and gradient of the vertex targets from
+        ``k2b_vertex_term``, then one ``k2b_adam_step`` over the packed parameters (the same arithmetic as the fused
+        kernel's update).  Returns the same dict as ``native.fit_world``; ``loss`` is the loss of the last iteration
+        before its step (``world_space.py:256``)."""
+        kin_idx, tgt_k, conf_k, vtx_idx, tgt_v, conf_v = self._split_targets(model_idx, tgt, conf)
         num_iters, lr = int(cfg.num_iters), float(cfg.step_size)
         cfg.num_iters, cfg.step_size = 1, 0.0                     # evaluate-only launches of the fused kernel
         B, D, NB = go.shape[0], bp.shape[1], be.shape[1]
@@ -201,6 +202,9 @@ class WorldSpaceFitter:
         cfg.num_iters, cfg.step_size = 1, 0.0          # evaluate-only launches
         B, D = go.shape[0], bp.shape[1]
         NB = be.shape[1]
+        vtx_idx = []
+        if any(i >= self.smpl.num_joints for i in model_idx):      # vertex-selected joints: their term comes from k2b_vertex_term
+            model_idx, tgt, conf, vtx_idx, tgt_v, conf_v = self._split_targets(model_idx, tgt, conf)
         preserve = bp.clone()                          # world_space.py:159
         outs = {k: [] for k in ("global_orient", "body_pose", "betas", "transl", "loss")}
         for f in range(B):
@@ -216,10 +220,17 @@ class WorldSpaceFitter:
 
             def evaluate(want_grad):
                 with torch.no_grad():
-                    return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt[sl].contiguous(),
-                                            cf, p[0].detach().contiguous(), p[1].detach().contiguous(),
-                                            beta.detach().contiguous(), p[2].detach().contiguous(),
-                                            preserve_pose=pres, want_grad=want_grad)
+                    cur = (p[0].detach().contiguous(), p[1].detach().contiguous(), beta.detach().contiguous(),
+                           p[2].detach().contiguous())
+                    r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt[sl].contiguous(),
+                                         cf, *cur, preserve_pose=pres, want_grad=want_grad)
+                    if vtx_idx:
+                        loss_v, grad_v = native.vertex_term(self.smpl.native, vtx_idx, tgt_v[sl].contiguous(), conf_v,
+                                                            float(cfg.sigma), float(cfg.joint_loss_weight), *cur)
+                        r["loss"] = r["loss"] + loss_v
+                        if want_grad:
+                            r["grad"] = r["grad"] + grad_v
+                    return r
 
             def closure():
                 r = evaluate(True)

