@@ -70,6 +70,7 @@ struct k2b_model {
     float *dt = nullptr, *dd = nullptr;
     int* tree = nullptr;
     int* sel_ws = nullptr;                                   // device copy of the selected extra-joint indices (vertex term)
+    std::vector<int> sel_host;                               // ... and what it currently holds
     std::vector<int> depth;                                  // depth of every joint (root 0)
     // LBS B operands (f16 hi/lo, MFMA fragment order) for the whole mesh and for the E extra-joint vertices
     struct VertexSet {
@@ -597,11 +598,16 @@ int k2b_vertex_term(const k2b_model* model_c, int32_t B, int32_t E_sel, const in
             return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: extra_index[%d]=%d outside [0,%d)", e, extra_index[e], m->E);
     hipStream_t stream = (hipStream_t)stream_v;
     {
+        // the selection is uploaded only when it changes (an Adam loop calls this once per iteration with the same one)
         std::lock_guard<std::mutex> lk(m->mu);
         if (!m->sel_ws) HIP_TRY(hipMalloc((void**)&m->sel_ws, 32 * sizeof(int)));
+        const std::vector<int> want(extra_index, extra_index + E_sel);
+        if (want != m->sel_host) {
+            HIP_TRY(hipStreamSynchronize(stream));                  // earlier launches may still read the old selection
+            HIP_TRY(hipMemcpy(m->sel_ws, want.data(), (size_t)E_sel * sizeof(int), hipMemcpyHostToDevice));
+            m->sel_host = want;
+        }
     }
-    HIP_TRY(hipMemcpyAsync(m->sel_ws, extra_index, (size_t)E_sel * sizeof(int), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));     // extra_index is the caller's host memory
     k2b::VertexTermArgs a{};
     a.v_template = m->v_template; a.shapedirs = m->shapedirs; a.posedirs = m->posedirs; a.lbs_weights = m->lbs_weights;
     a.j_template = m->j_template; a.j_dirs = m->j_dirs; a.parents = m->parents; a.extra_ids = m->extra_ids;
