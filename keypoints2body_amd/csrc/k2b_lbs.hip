@@ -48,6 +48,8 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // ---------------------------------------------------------------------------------------------
 // Pose set-up: one 64-lane workgroup per frame, lane j = joint j.
 // ---------------------------------------------------------------------------------------------
+constexpr int kMaxXSteps = 24;       // 16-deep k-steps of the feature vector this kernel can stage (SMPL: 14 or 16)
+
 __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     __shared__ float sR[kMaxJoints][9];
     __shared__ float sd[kMaxJoints][3];
@@ -88,13 +90,17 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     }
     __syncthreads();
 
-    // X operand of the vertex GEMM, f16 hi/lo, fragments [ks][frame tile]
+    // The f16 hi/lo operands of this frame are staged in LDS in k order and leave as 16-byte chunks: inside a
+    // fragment the eight k values of one (h, frame) pair are contiguous (frag_elem), so a frame owns 4 chunks
+    // per X k-step and 8 per (entry, joint k-step) of A.  (Element-wise 2-byte stores - 1200 per frame - made
+    // this kernel store-issue bound.)
+    __shared__ __attribute__((aligned(16))) _Float16 sXh[kMaxXSteps * 16], sXl[kMaxXSteps * 16];
+    __shared__ __attribute__((aligned(16))) _Float16 sAh[12][32], sAl[12][32];
     auto put_x = [&](int k, float x) {
         _Float16 hi, lo;
         split_f16(x, hi, lo);
-        const size_t o = frag_elem((size_t)(k >> 4) * (bp >> 5) + (f >> 5), k, f);
-        a.xh[o] = hi;
-        a.xl[o] = lo;
+        sXh[k] = hi;
+        sXl[k] = lo;
     };
     const int P = 9 * (J - 1);
     if (act && j > 0) {
@@ -104,36 +110,49 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         const float x = k < P + NB ? a.be[(size_t)f * NB + (k - P)] : (k < P + NB + 2 ? 1.f : 0.f);
         put_x(k, x);
     }
-    // zero rows of the A operand for the padded joints J .. 16*k_steps_a - 1
-    for (int idx = j; idx < (a.k_steps_a * 16 - J) * 12; idx += 64) {
-        const int jj = J + idx / 12, e = idx % 12;
-        const size_t o = frag_elem(a_frag(e, jj >> 4, a.k_steps_a, bp >> 5, f >> 5), jj, f);
-        a.ah[o] = (_Float16)0.f;
-        a.al[o] = (_Float16)0.f;
-    }
-    if (!act) return;
 
     // global transform: compose towards the root
     Mat3 Rg = rod.R;
-    Vec3 pg = {sd[j][0], sd[j][1], sd[j][2]};
-    for (int anc = par; anc >= 0; anc = spar[anc]) {
-        Mat3 Ra;
-        for (int i = 0; i < 9; ++i) Ra.m[i] = sR[anc][i];
-        const Vec3 da = {sd[anc][0], sd[anc][1], sd[anc][2]};
-        pg = mul(Ra, pg) + da;
-        Rg = mul(Ra, Rg);
+    Vec3 pg = {0.f, 0.f, 0.f};
+    if (act) {
+        pg = {sd[j][0], sd[j][1], sd[j][2]};
+        for (int anc = par; anc >= 0; anc = spar[anc]) {
+            Mat3 Ra;
+            for (int i = 0; i < 9; ++i) Ra.m[i] = sR[anc][i];
+            const Vec3 da = {sd[anc][0], sd[anc][1], sd[anc][2]};
+            pg = mul(Ra, pg) + da;
+            Rg = mul(Ra, Rg);
+        }
     }
-    // A_j = [Rg | pg - Rg J_j], f16 hi/lo, fragments [entry pair][ks][entry & 1][frame tile], k = joint
-    const Vec3 rj = mul(Rg, Jj);
-    const float At[12] = {Rg.m[0], Rg.m[1], Rg.m[2], pg.x - rj.x, Rg.m[3], Rg.m[4], Rg.m[5], pg.y - rj.y,
-                          Rg.m[6], Rg.m[7], Rg.m[8], pg.z - rj.z};
-    for (int e = 0; e < 12; ++e) {
-        _Float16 hi, lo;
-        split_f16(At[e], hi, lo);
-        const size_t o = frag_elem(a_frag(e, j >> 4, a.k_steps_a, bp >> 5, f >> 5), j, f);
-        a.ah[o] = hi;
-        a.al[o] = lo;
+    // A_j = [Rg | pg - Rg J_j] (k = joint; zero rows for the padded joints J .. 16 k_steps_a - 1)
+    if (j < 32) {
+        const Vec3 rj = mul(Rg, Jj);
+        const float At[12] = {Rg.m[0], Rg.m[1], Rg.m[2], pg.x - rj.x, Rg.m[3], Rg.m[4], Rg.m[5], pg.y - rj.y,
+                              Rg.m[6], Rg.m[7], Rg.m[8], pg.z - rj.z};
+        for (int e = 0; e < 12; ++e) {
+            _Float16 hi = (_Float16)0.f, lo = (_Float16)0.f;
+            if (act) split_f16(At[e], hi, lo);
+            sAh[e][j] = hi;
+            sAl[e][j] = lo;
+        }
     }
+    __syncthreads();
+    {
+        const int tiles = bp >> 5, tile = f >> 5;
+        const int nx = 2 * a.k_steps_x;                    // chunks per X array
+        for (int c = j; c < 2 * nx; c += 64) {
+            const int lo = c >= nx, kc = lo ? c - nx : c, ks = kc >> 1, h = kc & 1;
+            const uint4 v = *reinterpret_cast<const uint4*>((lo ? sXl : sXh) + ks * 16 + 8 * h);
+            *reinterpret_cast<uint4*>((lo ? a.xl : a.xh) + frag_elem((size_t)ks * tiles + tile, 8 * h, f)) = v;
+        }
+        const int na = 12 * a.k_steps_a * 2;               // chunks per A array
+        for (int c = j; c < 2 * na; c += 64) {
+            const int lo = c >= na, cc = lo ? c - na : c, e = cc / (a.k_steps_a * 2), r = cc % (a.k_steps_a * 2), ks = r >> 1, h = r & 1;
+            const uint4 v = *reinterpret_cast<const uint4*>((lo ? &sAl[e][0] : &sAh[e][0]) + ks * 16 + 8 * h);
+            *reinterpret_cast<uint4*>((lo ? a.al : a.ah) + frag_elem(a_frag(e, ks, a.k_steps_a, tiles, tile), 8 * h, f)) = v;
+        }
+    }
+    if (!act) return;
     if (a.joints_out) {
         float* o = a.joints_out + ((size_t)f * a.num_out_joints + j) * 3;
         const float tx = a.tr ? a.tr[(size_t)f * 3] : 0.f, ty = a.tr ? a.tr[(size_t)f * 3 + 1] : 0.f,
@@ -368,6 +387,7 @@ int lbs_frames_padded(int num_frames) { return (num_frames + 31) / 32 * 32; }
 
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
+    if (a.k_steps_x > kMaxXSteps || a.k_steps_a * 16 > 32 || a.num_joints > 32) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k2b_pose_setup_kernel, dim3(a.num_frames), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
