@@ -8,23 +8,31 @@ shutil.copy(glob.glob(O + '/stats1024/*/*kernel_stats.csv')[0], 'profiles/r01_fi
 shutil.copy(glob.glob(O + '/stats4096/*/*kernel_stats.csv')[0], 'profiles/r01_final_kernel_stats_4096f.csv')
 for n in ('bench_1024', 'bench_4096', 'bench_1024_under_rocprof', 'bench_4096_under_rocprof'):
     shutil.copy(f'{O}/{n}.json', f'profiles/r01_final_{n}.json')
-out, vals = [], {}
-for name in ('fetch1024', 'write1024'):
-    for d in glob.glob(f'{O}/{name}/*/*counter_collection.csv'):
-        for r in csv.DictReader(open(d)):
-            if 'k2b' in r['Kernel_Name']:
-                kn = r['Kernel_Name'].split('(')[0]
-                out.append((kn, r['Grid_Size'], r['Counter_Name'], r['Counter_Value']))
-                if 'fit_world' in kn or ('lbs_mfma' in kn and int(r['Grid_Size']) > 100000):
-                    vals.setdefault(('fit' if 'fit_world' in kn else 'lbs', r['Counter_Name']), []).append(float(r['Counter_Value']))
-with open('profiles/r01_final_hbm_pmc_1024f.csv', 'w') as f:
-    f.write('kernel,grid_size,counter,value_KiB\n')
-    for o in out: f.write(','.join(o) + '\n')
-avg = {k: sum(v) / len(v) for k, v in vals.items()}
-print(avg)
-t = {"_doc": "HBM bytes per launch at 1024 frames from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for wide coalesced reads). KiB -> bytes.",
-     "fit_frames_1024": int((2 * avg[('fit', 'FETCH_SIZE')] + avg[('fit', 'WRITE_SIZE')]) * 1024),
-     "lbs_frames_1024": int((2 * avg[('lbs', 'FETCH_SIZE')] + avg[('lbs', 'WRITE_SIZE')]) * 1024)}
+t = {"_doc": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for wide coalesced reads). KiB -> bytes."}
+for frames in ('1024', '4096'):
+    out, vals = [], {}
+    for name in (f'fetch{frames}', f'write{frames}'):
+        for d in glob.glob(f'{O}/{name}/*/*counter_collection.csv'):
+            for r in csv.DictReader(open(d)):
+                if 'k2b' in r['Kernel_Name']:
+                    kn = r['Kernel_Name'].split('(')[0]
+                    out.append((kn, r['Grid_Size'], r['Counter_Name'], r['Counter_Value']))
+                    if 'fit_world' in kn or 'lbs_mfma' in kn:
+                        vals.setdefault(('fit' if 'fit_world' in kn else 'lbs', r['Counter_Name']), []).append((int(r['Grid_Size']), float(r['Counter_Value'])))
+    if not vals:
+        continue
+    with open(f'profiles/r01_final_hbm_pmc_{frames}f.csv', 'w') as f:
+        f.write('kernel,grid_size,counter,value_KiB\n')
+        for o in out: f.write(','.join(o) + '\n')
+    # full-mesh launches only: the LBS kernel also runs on the 21 vertex-selected joints with a small grid
+    avg = {}
+    for k, v in vals.items():
+        gmax = max(g for g, _ in v)
+        sel = [x for g, x in v if g == gmax]
+        avg[k] = sum(sel) / len(sel)
+    print(frames, avg)
+    t[f"fit_frames_{frames}"] = int((2 * avg[('fit', 'FETCH_SIZE')] + avg[('fit', 'WRITE_SIZE')]) * 1024)
+    t[f"lbs_frames_{frames}"] = int((2 * avg[('lbs', 'FETCH_SIZE')] + avg[('lbs', 'WRITE_SIZE')]) * 1024)
 json.dump(t, open('profiles/traffic_r01.json', 'w'), indent=1)
 print(t)
 for n in ('1024', '4096'):
