@@ -53,6 +53,71 @@ def guess_init_transl_from_root(smpl_model, pose_aa, betas, j3d_world_frame, joi
     return (target[:, root_target, :] - out.joints[:, root_model, :]).detach()
 
 
+def split_targets(smpl, model_idx, tgt, conf):
+    """Kinematic targets (fused kernel) and vertex-selected ones (``k2b_vertex_term``) of a target list."""
+    J = smpl.num_joints
+    if conf is not None and conf.dim() == 2:
+        raise NotImplementedError("per-frame confidences with vertex-selected joints")
+    kin = [k for k, i in enumerate(model_idx) if i < J]
+    vtx = [k for k, i in enumerate(model_idx) if i >= J]
+    if not kin:
+        raise NotImplementedError("at least one kinematic joint (model index < %d) must be among the targets" % J)
+    num_extra = smpl.native.num_extra
+    if any(model_idx[k] - J >= num_extra for k in vtx):
+        raise ValueError(f"target_model_indices must be < {J + num_extra}")
+    pick = lambda rows: None if conf is None else conf[rows].contiguous()
+    return ([model_idx[k] for k in kin], tgt[:, kin].contiguous(), pick(kin),
+            [model_idx[k] - J for k in vtx], tgt[:, vtx].contiguous(), pick(vtx))
+
+
+def evaluate_with_vertex_joints(smpl, prior, cfg, split, go, bp, be, tr, preserve_pose=None, want_grad=True,
+                                transl_prior_target=None):
+    """Loss (and gradient) at the given parameters when some targets are vertex-selected joints: the kinematic
+    targets and every prior from an evaluate-only launch of the fused kernel (``cfg`` must have ``num_iters = 1``,
+    ``step_size = 0``), the vertex targets from ``k2b_vertex_term``.  ``split`` is ``split_targets``' result."""
+    kin_idx, tgt_k, conf_k, vtx_idx, tgt_v, conf_v = split
+    ev = native.fit_world(smpl.native, prior.native, cfg, kin_idx, tgt_k, conf_k, go, bp, be, tr,
+                          preserve_pose=preserve_pose, want_grad=want_grad, transl_prior_target=transl_prior_target)
+    loss_v, grad_v = native.vertex_term(smpl.native, vtx_idx, tgt_v, conf_v, float(cfg.sigma), float(cfg.joint_loss_weight),
+                                        go, bp, be, tr)
+    out = {"loss": ev["loss"] + loss_v}
+    if want_grad:
+        out["grad"] = ev["grad"] + grad_v
+    return out
+
+
+def adam_with_vertex_joints(smpl, prior, cfg, model_idx, tgt, conf, go, bp, be, tr, transl_prior_target=None):
+    """The Adam loop driven from the host, for target lists with vertex-selected joints.  Per iteration: loss and
+    gradient from ``evaluate_with_vertex_joints`` (two launches), then one ``k2b_adam_step`` over the packed
+    parameters (the same arithmetic as the fused kernel's update; parameters outside ``cfg.optimize_mask`` get no
+    gradient).  Returns the same dict as ``native.fit_world``; ``loss`` is the loss of the last iteration before
+    its step (``world_space.py:256``).  ``cfg`` is left in its evaluate-only state."""
+    split = split_targets(smpl, model_idx, tgt, conf)
+    num_iters, lr = int(cfg.num_iters), float(cfg.step_size)
+    cfg.num_iters, cfg.step_size = 1, 0.0                     # evaluate-only launches of the fused kernel
+    B, D, NB = go.shape[0], bp.shape[1], be.shape[1]
+    cols = (slice(0, 3), slice(3, 3 + D), slice(3 + D, 3 + D + NB), slice(3 + D + NB, 3 + D + NB + 3))
+    params = torch.cat([go, bp, be, tr], dim=1).contiguous()
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    preserve = bp.clone()
+    mask = int(cfg.optimize_mask) & (~4 if cfg.freeze_betas else ~0)
+    loss = None
+    for step in range(1, num_iters + 1):
+        p = [params[:, c].contiguous() for c in cols]
+        ev = evaluate_with_vertex_joints(smpl, prior, cfg, split, *p, preserve_pose=preserve,
+                                         transl_prior_target=transl_prior_target)
+        grad = ev["grad"]
+        for bit, c in zip((1, 2, 4, 8), cols):                # parameters outside the optimiser get no gradient
+            if not (mask & bit):
+                grad[:, c] = 0.0
+        loss = ev["loss"]
+        native.adam_step(params, grad.contiguous(), m, v, step, lr, float(cfg.adam_beta1), float(cfg.adam_beta2),
+                         float(cfg.adam_eps))
+    out = {k: params[:, c].contiguous() for k, c in zip(("global_orient", "body_pose", "betas", "transl"), cols)}
+    out["loss"] = loss if loss is not None else torch.zeros(B, device=params.device)
+    return out
+
+
 class WorldSpaceFitter:
     """Per-frame optimizer operating in world coordinates, executed on one MI355X."""
 
@@ -146,53 +211,12 @@ class WorldSpaceFitter:
         return out, joints, verts, out["loss"]
 
     def _split_targets(self, model_idx, tgt, conf):
-        """Kinematic targets (fused kernel) and vertex-selected ones (``k2b_vertex_term``) of a target list."""
-        J = self.smpl.num_joints
-        if conf is not None and conf.dim() == 2:
-            raise NotImplementedError("per-frame confidences with vertex-selected joints")
-        kin = [k for k, i in enumerate(model_idx) if i < J]
-        vtx = [k for k, i in enumerate(model_idx) if i >= J]
-        if not kin:
-            raise NotImplementedError("at least one kinematic joint (model index < %d) must be among the targets" % J)
-        num_extra = self.smpl.native.num_extra
-        if any(model_idx[k] - J >= num_extra for k in vtx):
-            raise ValueError(f"target_model_indices must be < {J + num_extra}")
-        pick = lambda rows: None if conf is None else conf[rows].contiguous()
-        return ([model_idx[k] for k in kin], tgt[:, kin].contiguous(), pick(kin),
-                [model_idx[k] - J for k in vtx], tgt[:, vtx].contiguous(), pick(vtx))
+        return split_targets(self.smpl, model_idx, tgt, conf)
 
     def _fit_with_vertex_joints(self, cfg, model_idx, tgt, conf, go, bp, be, tr):
         """Adam branch with vertex-selected joints among the targets (``world_space.py:198-201`` with indices
-        >= 24): the host drives the iterations.  Per iteration: loss and gradient of the kinematic targets and of
-        every prior from an evaluate-only launch of the fused kernel, loss and gradient of the vertex targets from
-        ``k2b_vertex_term``, then one ``k2b_adam_step`` over the packed parameters (the same arithmetic as the fused
-        kernel's update).  Returns the same dict as ``native.fit_world``; ``loss`` is the loss of the last iteration
-        before its step (``world_space.py:256``)."""
-        kin_idx, tgt_k, conf_k, vtx_idx, tgt_v, conf_v = self._split_targets(model_idx, tgt, conf)
-        num_iters, lr = int(cfg.num_iters), float(cfg.step_size)
-        cfg.num_iters, cfg.step_size = 1, 0.0                     # evaluate-only launches of the fused kernel
-        B, D, NB = go.shape[0], bp.shape[1], be.shape[1]
-        cols = (slice(0, 3), slice(3, 3 + D), slice(3 + D, 3 + D + NB), slice(3 + D + NB, 3 + D + NB + 3))
-        params = torch.cat([go, bp, be, tr], dim=1).contiguous()
-        m, v = torch.zeros_like(params), torch.zeros_like(params)
-        preserve = bp.clone()
-        mask = int(cfg.optimize_mask) & (~4 if cfg.freeze_betas else ~0)
-        loss = None
-        for step in range(1, num_iters + 1):
-            p = [params[:, c].contiguous() for c in cols]
-            ev = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, kin_idx, tgt_k, conf_k, p[0], p[1], p[2], p[3],
-                                  preserve_pose=preserve, want_grad=True)
-            loss_v, grad_v = native.vertex_term(self.smpl.native, vtx_idx, tgt_v, conf_v, float(cfg.sigma),
-                                                float(cfg.joint_loss_weight), p[0], p[1], p[2], p[3])
-            for bit, c in zip((1, 2, 4, 8), cols):                # parameters outside the optimiser get no gradient
-                if not (mask & bit):
-                    grad_v[:, c] = 0.0
-            grad = (ev["grad"] + grad_v).contiguous()
-            loss = ev["loss"] + loss_v
-            native.adam_step(params, grad, m, v, step, lr, float(cfg.adam_beta1), float(cfg.adam_beta2), float(cfg.adam_eps))
-        out = {k: params[:, c].contiguous() for k, c in zip(("global_orient", "body_pose", "betas", "transl"), cols)}
-        out["loss"] = loss if loss is not None else torch.zeros(B, device=params.device)
-        return out
+        >= 24): see ``adam_with_vertex_joints``."""
+        return adam_with_vertex_joints(self.smpl, self.pose_prior, cfg, model_idx, tgt, conf, go, bp, be, tr)
 
     def _fit_lbfgs(self, cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas):
         """LBFGS branch (world_space.py:231-247): ``torch.optim.LBFGS(params, max_iter=num_iters,

@@ -20,7 +20,9 @@ that its ``__init__`` (which needs the absent ``h5py``/``smplx``) is not execute
 Outputs: ``tests/golden/world_fit_*.npz`` (inputs + reference outputs) and
 ``tests/golden/gmm_synth.npz`` (mixture + the buffers the reference derived).
 
-Usage:  python oracle/gen_golden.py
+Usage:  python oracle/gen_golden.py [--only SUBSTRING]
+(``--only`` still runs every case - they share seeded state - but writes only the files whose name contains
+SUBSTRING, so that adding a case does not rewrite the zip timestamps of the other fixtures.)
 """
 from __future__ import annotations
 
@@ -174,6 +176,15 @@ def run_case(name, ref, model, *, init, j3d, conf, seq_ind, num_iters, category,
 
 def main():
     global model_fingerprint
+    if "--only" in sys.argv:
+        only, real_save = sys.argv[sys.argv.index("--only") + 1], np.savez_compressed
+
+        def filtered_save(path, **kw):
+            if only in Path(path).name:
+                real_save(path, **kw)
+            else:
+                print(f"[golden] (not written: {Path(path).name})")
+        np.savez_compressed = filtered_save
     torch.manual_seed(0)
     torch.set_num_threads(8)
     GOLDEN.mkdir(parents=True, exist_ok=True)
@@ -315,6 +326,37 @@ def main():
             out_transl=cat(outs["tr"]), out_joints=cat(outs["joints"]), out_loss=cat(outs["loss"]),
             out_verts_sampled=cat(outs["verts_sampled"]), sampled_vertex_ids=sample_vertex_ids(6890))
         print(f"[golden] camera {name}: iters={iters} losses={cat(outs['loss'])}")
+
+    # ---- camera fitter, GENERIC targets with vertex-selected joints (model index >= 24) in both stages --------
+    fitter = CameraSpaceFitter(model, step_size=1e-2, num_iters=30, use_lbfgs=False,
+                               joints_category="GENERIC", device=torch.device("cpu"))
+    outs = {k: [] for k in ("go", "bp", "be", "tr", "joints", "loss", "verts_sampled", "t0")}
+    n = 2
+    conf8 = torch.ones(27); conf8[[4, 23]] = 0.6
+    for i in range(n):
+        sl = slice(i, i + 1)
+        with torch.no_grad():
+            j0 = model(global_orient=init7["global_orient"][sl], body_pose=init7["body_pose"][sl], betas=init7["betas"][sl]).joints
+        t0 = (jgen8[sl, 0] - j0[:, int(idx8[0])]) + off
+        outs["t0"].append(t0)
+        res = fitter.fit_frame(SMPLData(betas=init7["betas"][sl], global_orient=init7["global_orient"][sl],
+                                        body_pose=init7["body_pose"][sl]),
+                               jgen8[sl], conf_3d=conf8, seq_ind=0, target_model_indices=idx8, joint_loss_weight=600.0,
+                               pose_preserve_weight=5.0, freeze_betas=False, init_cam_t=t0)
+        p = res.params
+        outs["go"].append(p.global_orient); outs["bp"].append(p.body_pose); outs["be"].append(p.betas)
+        outs["tr"].append(p.transl); outs["joints"].append(res.joints); outs["loss"].append(res.loss.reshape(1))
+        outs["verts_sampled"].append(res.vertices[:, sample_vertex_ids(res.vertices.shape[1])])
+    cat = lambda xs: torch.cat(xs, dim=0).detach().numpy()
+    np.savez_compressed(
+        GOLDEN / "camera_fit_generic_vertex_joints.npz", case="generic_vertex_joints", num_iters=30, seq_ind=0, freeze_betas=0,
+        has_conf=1, conf=conf8.numpy(), model_fingerprint=np.uint64(model_fingerprint), target_model_indices=idx8.numpy(),
+        init_global_orient=init7["global_orient"][:n].numpy(), init_body_pose=init7["body_pose"][:n].numpy(),
+        init_betas=init7["betas"][:n].numpy(), j3d=jgen8[:n].numpy(), has_init_cam_t=1, init_cam_t=cat(outs["t0"]),
+        out_global_orient=cat(outs["go"]), out_body_pose=cat(outs["bp"]), out_betas=cat(outs["be"]),
+        out_transl=cat(outs["tr"]), out_joints=cat(outs["joints"]), out_loss=cat(outs["loss"]),
+        out_verts_sampled=cat(outs["verts_sampled"]), sampled_vertex_ids=sample_vertex_ids(6890))
+    print(f"[golden] camera generic_vertex_joints: losses={cat(outs['loss'])}")
 
     # ---- LBFGS branch of the camera-space fitter ---------------------------------------------------------
     for name, iters, seq_ind, freeze in (("first", 20, 0, False), ("followup_frozen", 10, 3, True)):

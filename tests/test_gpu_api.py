@@ -196,6 +196,35 @@ def test_vertex_selected_joints_match_reference_golden(assets):
     assert err(joints_l, out_l["transl"]) < 1.5 * err(joints, out["transl"]) + 1e-3
 
 
+def test_camera_fitter_vertex_selected_joints_match_reference_golden(assets):
+    """Camera-space fitter with GENERIC targets that include vertex-selected joints (model indices >= 24) in BOTH
+    stages (reference ``camera_space.py:199-210, 283-287``): the host-driven slow path must land on the reference's
+    parameters, joints, vertices and re-evaluated loss at the usual 1e-4."""
+    from keypoints2body_amd.core.fitters.camera_space import CameraSpaceFitter
+    model, prior = assets
+    d = dict(np.load(H.GOLDEN / "camera_fit_generic_vertex_joints.npz"))
+    idx = torch.tensor(d["target_model_indices"])
+    assert int((idx >= 24).sum()) == 5
+    t = lambda k: torch.tensor(d[k])
+    fitter = CameraSpaceFitter(model, step_size=1e-2, num_iters=int(d["num_iters"]), use_lbfgs=False,
+                               joints_category="GENERIC", pose_prior=prior)
+    init = k2b.SMPLData(betas=t("init_betas"), global_orient=t("init_global_orient"), body_pose=t("init_body_pose"))
+    res = fitter.fit_frame(init, t("j3d"), conf_3d=t("conf"), seq_ind=0, target_model_indices=idx, freeze_betas=False,
+                           init_cam_t=t("init_cam_t"))
+    for key in ("global_orient", "body_pose", "betas", "transl"):
+        err = np.abs(getattr(res.params, key).cpu().numpy() - d["out_" + key]).max()
+        assert err < TOL, (key, err)
+    assert np.abs(res.joints.cpu().numpy() - d["out_joints"]).max() < TOL
+    vs = res.vertices[:, torch.as_tensor(d["sampled_vertex_ids"]).cuda()].cpu().numpy()
+    assert np.abs(vs - d["out_verts_sampled"]).max() < TOL
+    np.testing.assert_allclose(float(res.loss), float(d["out_loss"].sum()), rtol=2e-5)
+    # the LBFGS branches take the same vertex term in their closures: must run and stay finite
+    lb = CameraSpaceFitter(model, step_size=1e-2, num_iters=5, use_lbfgs=True, joints_category="GENERIC", pose_prior=prior)
+    one = k2b.SMPLData(betas=t("init_betas")[:1], global_orient=t("init_global_orient")[:1], body_pose=t("init_body_pose")[:1])
+    r = lb.fit_frame(one, t("j3d")[:1], conf_3d=t("conf"), seq_ind=0, target_model_indices=idx, init_cam_t=t("init_cam_t")[:1])
+    assert torch.isfinite(r.loss) and torch.isfinite(r.params.body_pose).all()
+
+
 @pytest.mark.parametrize("case", ["first", "followup_frozen"])
 def test_lbfgs_camera_fit_matches_reference_golden(assets, case):
     """LBFGS branches of the camera-space fitter (both stages).  Same statistical gate as the world LBFGS
