@@ -285,3 +285,84 @@ def test_vertex_joint_term_gradient_matches_autograd():
     for name, sl in (("global_orient", slice(0, 3)), ("body_pose", slice(3, 72)), ("betas", slice(72, 82)), ("transl", slice(82, 85))):
         scale = np.abs(g_ref[:, sl]).max()
         assert np.abs(g[:, sl] - g_ref[:, sl]).max() / scale < 5e-5, name
+
+
+def _random_configuration(seed):
+    """One seeded fitting problem with everything the path branches on drawn at random: batch size, iteration
+    count, target subset and order, confidences (zeros and values above 1), every loss weight (some zero), the
+    GMoF sigma, frozen shape, first / follow-up frame, and the kind of start (zeros, a perturbed copy of the true
+    pose, rotations of almost pi)."""
+    from keypoints2body_amd import synthetic
+    rng = np.random.default_rng(seed)
+    B = int(rng.integers(1, 8))
+    K = int(rng.integers(6, 25))
+    model_idx = sorted(rng.choice(24, size=K, replace=False).tolist())
+    model_idx = [model_idx[i] for i in rng.permutation(K)]
+    if 0 not in model_idx:                      # keep the root observed so that the translation is determined
+        model_idx[0] = 0
+    p = synthetic.make_poses(B, seed=100 + seed)
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32)
+    truth = dict(global_orient=t(p.global_orient), body_pose=t(p.body_pose), betas=t(p.betas), transl=t(p.transl))
+    kind = ("zeros", "perturbed", "large")[seed % 3]
+    if kind == "zeros":
+        init = dict(global_orient=torch.zeros(B, 3), body_pose=torch.zeros(B, 69), betas=torch.zeros(B, 10))
+    elif kind == "perturbed":
+        init = dict(global_orient=truth["global_orient"] + 0.1, body_pose=truth["body_pose"] * 0.7 + 0.02,
+                    betas=truth["betas"] * 0.3)
+        init["body_pose"][:, 6:12] = 0.0        # a few joints exactly at the identity rotation
+    else:
+        axis = t(rng.standard_normal((B, 3))); axis = axis / axis.norm(dim=1, keepdim=True)
+        init = dict(global_orient=axis * 3.1, body_pose=truth["body_pose"] * 1.5, betas=t(rng.uniform(-2, 2, (B, 10))))
+    conf = t(rng.choice([0.0, 0.5, 1.0, 1.5], size=K, p=[0.15, 0.2, 0.45, 0.2]))
+    conf[model_idx.index(0)] = 1.0
+    pick = lambda *v: float(rng.choice(v))
+    weights = dict(sigma=pick(30.0, 100.0, 300.0), pose_prior_weight=pick(0.0, 4.78 * 1.5, 12.0),
+                   shape_prior_weight=pick(0.0, 5.0, 20.0), angle_prior_weight=pick(0.0, 15.2),
+                   joint_loss_weight=pick(100.0, 600.0), pose_preserve_weight=pick(1.0, 5.0))
+    return dict(B=B, iters=int(rng.integers(3, 31)), model_idx=model_idx, conf=conf if seed % 4 else None,
+                truth=truth, init=init, weights=weights, seq_ind=int(seed % 2) * 3, freeze_betas=bool(seed % 5 == 0),
+                noise=t(0.01 * rng.standard_normal((B, K, 3))), kind=kind)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_configurations_match_oracle(seed, monkeypatch):
+    """Seeded sweep over the configuration space against the oracle (itself pinned to the reference on the golden
+    cases), each case in one of the three launch shapes: parameters within 1e-4, last-iteration loss within 2e-4
+    relative."""
+    from keypoints2body_amd import native
+    shape = ("split", "split_paired", "paired")[(seed // 3) % 3]
+    monkeypatch.setenv("K2B_FIT_MODE", shape)
+    from oracle.fit_torch import FitWeights, fit_world_adam, guess_init_transl
+    c = _random_configuration(seed)
+    oracle = H.oracle_model()
+    with torch.no_grad():
+        joints = oracle(**c["truth"]).joints
+    j3d = joints[:, c["model_idx"]] + c["noise"]
+    init = c["init"]
+    with torch.no_grad():
+        j0 = oracle(global_orient=init["global_orient"], body_pose=init["body_pose"], betas=init["betas"]).joints
+    root = c["model_idx"].index(0)
+    tr0 = (j3d[:, root] - j0[:, 0]) + 0.01          # a start off the root-aligned one: no zero-gradient first step
+    ref = fit_world_adam(oracle, H.oracle_prior(), init["global_orient"], init["body_pose"], init["betas"], tr0, j3d,
+                         c["conf"], num_iters=c["iters"], seq_ind=c["seq_ind"], model_idx=c["model_idx"],
+                         weights=FitWeights(**c["weights"]), freeze_betas=c["freeze_betas"])
+    cfg = native.default_fit_config()
+    cfg.num_iters = c["iters"]
+    for k, v in c["weights"].items():
+        setattr(cfg, k, v)
+    if c["seq_ind"] == 0:
+        cfg.pose_preserve_weight = 0.0
+    cfg.freeze_betas = int(c["freeze_betas"])
+    out = native.fit_world(H.native_model(), H.native_prior(), cfg, c["model_idx"], j3d.cuda().contiguous(),
+                           None if c["conf"] is None else c["conf"].cuda(), init["global_orient"].cuda(),
+                           init["body_pose"].cuda().contiguous(), init["betas"].cuda(), tr0.cuda().contiguous())
+    tag = (seed, shape, c["kind"], c["B"], c["iters"], len(c["model_idx"]))
+    worst = 0.0
+    for key, want in (("global_orient", ref.global_orient), ("body_pose", ref.body_pose), ("betas", ref.betas), ("transl", ref.transl)):
+        err = (out[key].cpu() - want).abs().max().item()
+        worst = max(worst, err)
+        assert err < PARAM_TOL, (tag, key, err)
+    print(f"random configuration {tag}: worst parameter deviation {worst:.2e}")
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), ref.loss.numpy(), rtol=2e-4, err_msg=str(tag))
+    if c["freeze_betas"]:
+        assert torch.equal(out["betas"].cpu(), init["betas"])
