@@ -51,6 +51,31 @@ def test_lbs_matches_oracle_forward(with_transl):
     assert v2 is None and torch.equal(j, j2)
 
 
+@pytest.mark.parametrize("V,NB,B", [(64, 10, 1), (97, 10, 33), (500, 16, 129), (1000, 10, 257), (2049, 16, 31), (6890, 10, 130)])
+def test_lbs_ragged_sizes_match_oracle(V, NB, B):
+    """Mesh sizes and batches that are not multiples of the kernel's tiles (32-vertex / 32-frame MFMA tiles, 64 x 128
+    workgroup tiles) and both beta counts, with large rotations; against the oracle's forward on the same arrays."""
+    from keypoints2body_amd import synthetic
+    from keypoints2body_amd.native import NativeModel
+    from oracle.smpl_torch import TorchSMPL
+    c = synthetic.make_body_model(seed=11, num_vertices=V, num_betas=NB)
+    model = NativeModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents, c.extra_vertex_ids)
+    rng = np.random.default_rng(V + B)
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)
+    go, bp = t(rng.uniform(-3.0, 3.0, (B, 3))), t(0.6 * rng.standard_normal((B, 69)))
+    bp[0] = 0.0                                      # identity rotations in one frame
+    be, tr = t(rng.uniform(-2.5, 2.5, (B, NB))), t(rng.uniform(-5.0, 5.0, (B, 3)))
+    with torch.no_grad():
+        want = TorchSMPL(c)(global_orient=go, body_pose=bp, betas=be, transl=tr)
+    j, v = model.lbs(go.cuda(), bp.cuda().contiguous(), be.cuda(), tr.cuda())
+    scale = max(1.0, float(want.vertices.abs().max()))
+    assert v.shape == (B, V, 3) and j.shape[0] == B
+    assert (v.cpu() - want.vertices).abs().max().item() < 5e-6 * scale
+    assert (j.cpu() - want.joints).abs().max().item() < 5e-6 * scale
+    j2, _ = model.lbs(go.cuda(), bp.cuda().contiguous(), be.cuda(), tr.cuda(), want_vertices=False)
+    assert torch.equal(j, j2)
+
+
 def test_lbs_against_float64_twin():
     from keypoints2body_amd import synthetic
     from oracle.smpl_torch import smpl_forward_np
