@@ -322,3 +322,39 @@ def test_shape_pre_pass_and_default_config_sequence(assets):
     assert len(res) == 2 and all(torch.isfinite(r.loss) for r in res)
     err_cm = float((res[0].joints[:, :22].cpu() - torch.tensor(d["j3d"][:1])).norm(dim=-1).mean()) * 100
     assert err_cm < 5.0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_camera_fitter_random_configurations_match_oracle(assets, seed):
+    """Seeded sweep of the two-stage camera fit (iterations, first / follow-up frame, frozen shape, confidences with
+    zeros, start offset) against the oracle's restatement, which the camera goldens pin to the reference."""
+    from keypoints2body_amd import synthetic
+    from keypoints2body_amd.core.fitters.camera_space import CameraSpaceFitter
+    from oracle.fit_torch import fit_camera_adam_one, guess_init_cam_t
+    model, prior = assets
+    rng = np.random.default_rng(50 + seed)
+    B, iters = 3, int(rng.integers(5, 41))
+    seq_ind, freeze = int(seed % 2) * 2, bool(seed > 2)
+    p = synthetic.make_poses(B, seed=60 + seed)
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)
+    oracle = H.oracle_model()
+    with torch.no_grad():
+        j3d = oracle(global_orient=t(p.global_orient), body_pose=t(p.body_pose), betas=t(p.betas),
+                     transl=t(p.transl)).joints[:, :22] + t(0.01 * rng.standard_normal((B, 22, 3)))
+    go0, bp0, be0 = t(p.global_orient) + 0.15, t(p.body_pose) * 0.6, t(p.betas) * 0.5
+    conf = t(rng.choice([0.0, 0.7, 1.0, 1.5], size=22, p=[0.1, 0.2, 0.5, 0.2]))
+    conf[[1, 2, 16, 17]] = 1.0
+    with torch.no_grad():
+        j0 = oracle(global_orient=go0, body_pose=bp0, betas=be0).joints
+    t0 = guess_init_cam_t(j0[:, :22], j3d) + t(rng.uniform(0.02, 0.05, (1, 3)) * rng.choice([-1.0, 1.0], (1, 3)))
+    fitter = CameraSpaceFitter(model, step_size=1e-2, num_iters=iters, use_lbfgs=False, joints_category="AMASS", pose_prior=prior)
+    res = fitter.fit_frame(k2b.SMPLData(betas=be0, global_orient=go0, body_pose=bp0), j3d, conf_3d=conf, seq_ind=seq_ind,
+                           freeze_betas=freeze, init_cam_t=t0)
+    for f in range(B):
+        sl = slice(f, f + 1)
+        ref = fit_camera_adam_one(oracle, H.oracle_prior(), go0[sl], bp0[sl], be0[sl], j3d[sl], conf, num_iters=iters,
+                                  seq_ind=seq_ind, freeze_betas=freeze, init_cam_t=t0[sl])
+        for key, want in (("global_orient", ref.global_orient), ("body_pose", ref.body_pose), ("betas", ref.betas),
+                          ("transl", ref.transl)):
+            err = (getattr(res.params, key)[sl].cpu() - want).abs().max().item()
+            assert err < TOL, (seed, f, key, err)
