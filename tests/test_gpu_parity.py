@@ -135,6 +135,10 @@ def test_fit_matches_reference_golden(case):
     # final forward on the fitted parameters
     j, v = H.native_model().lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"])
     assert np.abs(j.cpu().numpy() - d["out_joints"]).max() < PARAM_TOL
+    # matched final joint error: mean distance fitted joint - target equals the reference's to 1e-5 m
+    idx = H.case_indices(d)
+    jerr = lambda joints: np.linalg.norm(joints[:, idx] - d["j3d"], axis=-1).mean()     # target row k <-> model joint idx[k]
+    assert abs(jerr(j.cpu().numpy()) - jerr(d["out_joints"])) < 1e-5, case
     vs = v[:, torch.as_tensor(d["sampled_vertex_ids"]).cuda()].cpu().numpy()
     assert np.abs(vs - d["out_verts_sampled"]).max() < PARAM_TOL
     assert np.abs(v.double().sum(dim=1).cpu().numpy() - d["out_verts_sum"]).max() < 6890 * 2e-5
