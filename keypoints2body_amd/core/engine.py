@@ -95,7 +95,7 @@ def upgrade_smpl_family_init_params(base: SMPLData, model_type: str, model, devi
 
 
 def optimize_shape_pass(model, seq_config: SequenceOptimizeConfig, init_mean_shape, init_mean_pose, data_tensor,
-                        confidence_input, device, pose_prior=None):
+                        confidence_input, device, pose_prior=None, dist=None):
     """Multi-frame shared-betas pre-pass (reference ``core/engine.py:217-262`` ->
     ``optimize_shape_multi_frame``, ``core/shape.py:10-115``).
 
@@ -109,6 +109,11 @@ def optimize_shape_pass(model, seq_config: SequenceOptimizeConfig, init_mean_sha
     the 10-vector.  The reference's Adam branch of this pass raises (``shape.py:10,110-113``:
     ``closure()`` under ``no_grad`` and no optimiser step), so ``use_lbfgs=False`` is rejected here
     with an explicit error instead.
+
+    ``dist`` (an initialised ``torch.distributed`` module, one process per GPU) shards the ``num_shape_frames``
+    frames over the ranks: every closure evaluation is then one launch over the rank's own block plus ONE
+    all-reduce of NB + 4 floats (``parallel.allreduce_shape_terms``); all ranks run the same
+    L-BFGS on the same reduced numbers and return the same betas.
     """
     if not seq_config.use_shape_optimization:
         return init_mean_shape
@@ -130,6 +135,13 @@ def optimize_shape_pass(model, seq_config: SequenceOptimizeConfig, init_mean_sha
     t_size = data_tensor.shape[0]
     n = t_size if (seq_config.num_shape_frames < 0 or seq_config.num_shape_frames >= t_size) else seq_config.num_shape_frames
     y = torch.as_tensor(data_tensor, dtype=torch.float32).to(dev)[:n]
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        from ..parallel import shard_bounds
+        lo, hi = shard_bounds(n, dist.get_world_size(), dist.get_rank())
+        y = y[lo:hi]
+        n = hi - lo                                            # may be 0 on trailing ranks of a short sequence
+    else:
+        dist = None
     targets = y[:, list(corr_index)].contiguous()
     conf = torch.as_tensor(confidence_input, dtype=torch.float32).to(dev)
     conf = (conf if conf.dim() == 1 else conf[0])[list(corr_index)].contiguous()
@@ -149,18 +161,25 @@ def optimize_shape_pass(model, seq_config: SequenceOptimizeConfig, init_mean_sha
 
     betas = torch.as_tensor(init_mean_shape, dtype=torch.float32).to(dev).clone().reshape(1, -1).requires_grad_(True)
 
+    from ..parallel import allreduce_shape_terms
+
     def closure():
         with torch.no_grad():
             b = betas.detach()
-            transl = (y[:, root_target] - (jt0 + jd0 @ b[0])).contiguous()         # root alignment, (n,3)
-            r = native.fit_world(m.native, prior.native, cfg, list(smpl_index), targets, conf, go, bp,
-                                 b.expand(n, -1).contiguous(), transl, want_grad=True)
-            g = r["grad"]
             nb = b.shape[1]
-            g_beta = g[:, 3 + bp.shape[1]:3 + bp.shape[1] + nb].sum(dim=0)
-            g_transl = g[:, 3 + bp.shape[1] + nb:].sum(dim=0)
+            if n > 0:
+                transl = (y[:, root_target] - (jt0 + jd0 @ b[0])).contiguous()     # root alignment, (n,3)
+                r = native.fit_world(m.native, prior.native, cfg, list(smpl_index), targets, conf, go, bp,
+                                     b.expand(n, -1).contiguous(), transl, want_grad=True)
+                g = r["grad"]
+                g_beta = g[:, 3 + bp.shape[1]:3 + bp.shape[1] + nb].sum(dim=0)
+                g_transl = g[:, 3 + bp.shape[1] + nb:].sum(dim=0)
+                loss = r["loss"].sum()
+            else:
+                g_beta, g_transl, loss = torch.zeros(nb, device=dev), torch.zeros(3, device=dev), torch.zeros((), device=dev)
+            loss, g_beta, g_transl = allreduce_shape_terms(loss, g_beta, g_transl, dist)
             betas.grad = (g_beta - jd0.t() @ g_transl).reshape(1, -1)              # d transl / d beta = -J_dirs[root]
-            return r["loss"].sum()
+            return loss
 
     torch.optim.LBFGS([betas], max_iter=int(seq_config.num_shape_iters), lr=1e-1,
                       line_search_fn="strong_wolfe").step(closure)

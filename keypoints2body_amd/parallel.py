@@ -7,6 +7,9 @@ The reference has no distributed code at all; what shards is its frame loop
 independent: per-frame fits as ``optimize_params_frame`` does them (``api/frame.py:213-219``,
 always ``seq_ind=0``) or a sequence with ``use_previous_frame_init=False``.
 
+(The optional shape pre-pass, which couples the frames through the shared betas, shards the same way with one
+all-reduce of NB + 4 floats per closure evaluation: ``allreduce_shape_terms``.)
+
 Collective: a single all-gather of the packed fitted parameters (+ per-frame loss):
 ``3J + NB + 3 + 1`` floats per frame (344 B for SMPL) — latency-bound on the fully
 connected xGMI mesh, so one direct ``all_gather_into_tensor`` (RCCL), never a ring
@@ -88,3 +91,15 @@ def fit_frames_sharded(fit_fn: Callable[[slice], Dict[str, torch.Tensor]], num_f
                           for r in range(world)]).to(gathered.device)
         gathered = gathered.index_select(0, keep)
     return unpack_outputs(gathered, num_betas, pose_dim)
+
+
+def allreduce_shape_terms(loss: torch.Tensor, g_beta: torch.Tensor, g_transl: torch.Tensor, dist=None):
+    """Sum over ranks of the shape pre-pass's per-shard terms (reference ``core/shape.py:75-101`` sums them over
+    all frames): scalar loss, d/d betas (NB,), summed d/d transl (3,).  One all-reduce of NB + 4 floats; every rank
+    receives the same bits, so the L-BFGS iterations that follow stay identical on all ranks with no broadcast."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return loss, g_beta, g_transl
+    nb = g_beta.numel()
+    buf = torch.cat([g_beta.reshape(-1), g_transl.reshape(-1), loss.reshape(1)]).contiguous()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf[nb + 3], buf[:nb], buf[nb:nb + 3]

@@ -92,3 +92,39 @@ def test_two_rank_sharded_fit_equals_single_process():
         for k, v in single.items():
             assert got[rank][k].shape == tuple(v.shape)
             assert np.abs(got[rank][k] - v.numpy()).max() < 2e-6, (rank, k)
+
+
+def _shape_terms_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7 + rank)
+        loss, gb, gt = torch.rand((), generator=g), torch.randn(10, generator=g), torch.randn(3, generator=g)
+        rl, rb, rt = parallel.allreduce_shape_terms(loss, gb, gt, dist)
+        q.put((rank, rl.item(), rb.numpy(), rt.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_shape_pass_terms_all_reduce_to_the_same_sum_on_every_rank():
+    """The shape pre-pass shards its frames and sums loss / d beta / d transl with ONE all-reduce per closure call."""
+    one = parallel.allreduce_shape_terms(torch.tensor(1.5), torch.ones(10), torch.ones(3), None)
+    assert float(one[0]) == 1.5 and one[1].shape == (10,) and one[2].shape == (3,)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shape_terms_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=100) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want = [0.0, np.zeros(10, np.float32), np.zeros(3, np.float32)]
+    for r in range(2):
+        g = torch.Generator().manual_seed(7 + r)
+        want[0] += torch.rand((), generator=g).item(); want[1] += torch.randn(10, generator=g).numpy(); want[2] += torch.randn(3, generator=g).numpy()
+    for rank, l, b, t in got:
+        assert abs(l - want[0]) < 1e-6 and np.abs(b - want[1]).max() < 1e-6 and np.abs(t - want[2]).max() < 1e-6
+    assert got[0][1] == got[1][1] and np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])
