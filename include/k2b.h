@@ -169,6 +169,8 @@ int k2b_lbs(const k2b_model *model, int32_t num_frames, const float *global_orie
  *   of  joint_loss_weight^2 conf_e^2 sum_xyz gmof(vertex_e + transl - target_e)  over the E_sel
  *   selected extra joints; extra_index HOST int32 [E_sel] in [0, E); targets dev [B][E_sel][3];
  *   conf dev [E_sel] or NULL.  At most 32 selected joints per call.
+ *   The selection is kept in a per-model device buffer (re-uploaded, after a stream sync, when it changes):
+ *   calls on one model that use DIFFERENT selections must not be in flight on different streams at once.
  * k2b_adam_step: torch.optim.Adam single-tensor update of n floats for step t = 1, 2, ...
  *   (bias corrections formed in double like the fused kernel's table); m, v are the caller's
  *   state buffers (zero before the first step).

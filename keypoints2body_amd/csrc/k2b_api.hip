@@ -143,6 +143,11 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         return fail(K2B_ERR_NO_DEVICE, "k2b_model_create: no HIP device visible (this engine has no CPU path)");
 
     k2b_model* m = new k2b_model;
+    // released (device buffers included) on every early return below; handed to the caller at the end
+    struct Guard {
+        k2b_model* m;
+        ~Guard() { if (m) k2b_model_destroy(m); }
+    } guard{m};
     m->V = V; m->J = J; m->NB = NB; m->E = E; m->P = 9 * (J - 1);
     HIP_TRY(upload(&m->v_template, v_template, (size_t)V * 3));
     HIP_TRY(upload(&m->shapedirs, shapedirs, (size_t)V * 3 * NB));
@@ -285,6 +290,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
     HIP_TRY(upload(&m->dd, dd.data(), dd.size()));
     HIP_TRY(upload(&m->tree, tab.data(), tab.size()));
     m->fit_ok = ok;
+    guard.m = nullptr;
     *out = m;
     return K2B_OK;
 }
