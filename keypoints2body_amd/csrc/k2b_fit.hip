@@ -884,8 +884,35 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     }
 }
 
+// the same call restricted to frames [f0, f0 + n): every per-frame array advanced by f0 frames
+static FitArgs frame_range(const FitArgs& a, int f0, int n) {
+    FitArgs r = a;
+    const size_t f = (size_t)f0, P = (size_t)(3 + D + a.num_betas + 3);
+    r.num_frames = n;
+    r.j3d = a.j3d + f * a.num_targets * 3;
+    if (a.conf && a.conf_per_frame) r.conf = a.conf + f * a.num_targets;
+    r.go_in = a.go_in + f * 3; r.bp_in = a.bp_in + f * D; r.be_in = a.be_in + f * a.num_betas; r.tr_in = a.tr_in + f * 3;
+    if (a.preserve) r.preserve = a.preserve + f * D;
+    if (a.tr_prior) r.tr_prior = a.tr_prior + f * 3;
+    r.go_out = a.go_out + f * 3; r.bp_out = a.bp_out + f * D; r.be_out = a.be_out + f * a.num_betas; r.tr_out = a.tr_out + f * 3;
+    if (a.loss_out) r.loss_out = a.loss_out + f;
+    if (a.grad_out) r.grad_out = a.grad_out + f * P;
+    return r;
+}
+
 hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     if (a_in.num_frames <= 0) return hipSuccess;
+    // More frames than one full-width launch of the densest shape holds (16 per CU): such a launch runs in rounds of
+    // num_cus workgroups, each as long as a full one however few workgroups it has (10 000 frames: 625 workgroups =
+    // 2.4 rounds, paid as 3).  Launch the whole rounds first and the remainder on its own, in the shape that suits
+    // ITS size (1 808 frames: split-paired, 0.6 of a paired round).  Frames are independent: results do not change.
+    const int full = MAXS * a_in.num_cus;
+    if (a_in.num_frames > full && a_in.num_frames % full != 0 && !getenv("K2B_FIT_MODE")) {
+        const int head = (a_in.num_frames / full) * full;
+        const hipError_t e = launch_fit_world(frame_range(a_in, 0, head), stream);
+        if (e != hipSuccess) return e;
+        return launch_fit_world(frame_range(a_in, head, a_in.num_frames - head), stream);
+    }
     FitArgs a = a_in;
     // frame slots per workgroup: enough to cover the batch with one workgroup per CU.  Up to 4: split
     // (SIMDs would idle, so every frame gets two cooperating waves); up to 8: one wave per frame;

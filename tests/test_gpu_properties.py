@@ -30,7 +30,7 @@ def _fit(j3d, tr0, iters=100, rows=None):
     return native.fit_world(H.native_model(), H.native_prior(), cfg, list(range(22)), j3d, None, z(3), z(69), z(10), tr0)
 
 
-@pytest.mark.parametrize("B", [1024, 2048, 4096, 10000])      # split, split-paired, paired, paired with a ragged tail
+@pytest.mark.parametrize("B", [1024, 2048, 4096, 8999, 10000])      # split, split-paired, paired, whole rounds + a remainder launch (split / split-paired)
 def test_full_size_fit_is_deterministic_independent_and_converges(B):
     j3d, tr0 = _problem(B)
     a, b = _fit(j3d, tr0), _fit(j3d, tr0)
