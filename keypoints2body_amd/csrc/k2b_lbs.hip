@@ -60,33 +60,43 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     const bool act = j < J;
     const int bp = a.frames_padded;
 
+    // Every load of this prologue is issued before the first use (fixed trip counts, predicated on k < NB): the kernel is
+    // one dependent chain per frame, and a loop of NB load -> fma round trips to L2 was a third of its time.
+    __shared__ float sJ[kMaxJoints][3];
     Vec3 th = {0.f, 0.f, 0.f};
-    Vec3 Jj = {0.f, 0.f, 0.f}, Jp = {0.f, 0.f, 0.f};
+    Vec3 Jj = {0.f, 0.f, 0.f};
     int par = -1;
     if (act) {
         const float* src = j == 0 ? a.go + (size_t)f * 3 : a.bp + (size_t)f * 3 * (J - 1) + 3 * (j - 1);
         th = {src[0], src[1], src[2]};
         par = a.parents[j];
-        float e[3], p[3] = {0.f, 0.f, 0.f};
+        float beta[kMaxBetas];
+#pragma unroll
+        for (int k = 0; k < kMaxBetas; ++k) beta[k] = k < NB ? a.be[(size_t)f * NB + k] : 0.f;
+        float e[3];
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
+            float dir[kMaxBetas];
+#pragma unroll
+            for (int k = 0; k < kMaxBetas; ++k) dir[k] = k < NB ? a.j_dirs[(j * 3 + c) * NB + k] : 0.f;
             float s = a.j_template[j * 3 + c];
-            for (int k = 0; k < NB; ++k) s += a.j_dirs[(j * 3 + c) * NB + k] * a.be[(size_t)f * NB + k];
+#pragma unroll
+            for (int k = 0; k < kMaxBetas; ++k) s += dir[k] * beta[k];      // same order of additions as before
             e[c] = s;
-            if (par >= 0) {
-                float q = a.j_template[par * 3 + c];
-                for (int k = 0; k < NB; ++k) q += a.j_dirs[(par * 3 + c) * NB + k] * a.be[(size_t)f * NB + k];
-                p[c] = q;
-            }
         }
         Jj = {e[0], e[1], e[2]};
-        Jp = {p[0], p[1], p[2]};
+        sJ[j][0] = e[0]; sJ[j][1] = e[1]; sJ[j][2] = e[2];
+        spar[j] = par;
     }
     const Rodrigues rod = rodrigues_fwd(th);
     if (act) {
         for (int i = 0; i < 9; ++i) sR[j][i] = rod.R.m[i];
+    }
+    __syncthreads();
+    if (act) {      // offset from the parent's rest joint (the parent's J(beta) comes from its own lane)
+        const Vec3 Jp = par >= 0 ? Vec3{sJ[par][0], sJ[par][1], sJ[par][2]} : Vec3{0.f, 0.f, 0.f};
         const Vec3 d = Jj - Jp;
         sd[j][0] = d.x; sd[j][1] = d.y; sd[j][2] = d.z;
-        spar[j] = par;
     }
     __syncthreads();
 
