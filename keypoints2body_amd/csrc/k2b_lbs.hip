@@ -236,12 +236,6 @@ __global__ __launch_bounds__(512, 1) void k2b_lbs_mfma_kernel(const SkinArgs a) 
     }
     const size_t astride = (size_t)4 * ftiles * kFragHalfs;
 
-    // ---- resident skinning weights: fragment (ks, vt, hl) -> wres[(ks * 2 + vt) * 2 + hl] ------------
-    for (int q = wave; q < KA * 4; q += 8) {
-        const int ks = q >> 2, vt = (q >> 1) & 1;
-        const _Float16* src = ((q & 1) ? a.wtl : a.wth) + ((size_t)ks * vtiles + vtile(vt)) * kFragHalfs + lane * 8;
-        *reinterpret_cast<half8*>(&wres[q][lane * 8]) = *reinterpret_cast<const half8*>(src);
-    }
 
     // Operand slices travel global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane x 16 B,
     // which is exactly the lane-linear 1 KiB fragment): no staging registers and no LDS writes in the waves'
@@ -271,6 +265,13 @@ __global__ __launch_bounds__(512, 1) void k2b_lbs_mfma_kernel(const SkinArgs a) 
 
     const int nslices = KS2 + 6;
     load_pose(0);
+    // ---- resident skinning weights: fragment (ks, vt, hl) -> wres[(ks * 2 + vt) * 2 + hl], requested together with the
+    // first slice (one round trip to L2 in front of the first barrier instead of two) ------------
+    for (int q = wave; q < KA * 4; q += 8) {
+        const int ks = q >> 2, vt = (q >> 1) & 1;
+        const _Float16* src = ((q & 1) ? a.wtl : a.wth) + ((size_t)ks * vtiles + vtile(vt)) * kFragHalfs + lane * 8;
+        __builtin_amdgcn_global_load_lds(src, &wres[q][0], 16, 0, 0);
+    }
     __syncthreads();
 
     // ---- phase 1: v_posed * kPdScale = X . Pd for the three coordinates -----------------------------
