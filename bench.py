@@ -2,21 +2,24 @@
 """Benchmark of the hot path: SMPL frames fitted per second (100 Adam iterations,
 22-joint AMASS targets) on N MI355X of one node.
 
-    python bench.py --gpus N --steps K --warmup W [--frames F] [--iters I]
+    python bench.py --gpus N --steps K --warmup W [--total-frames T | --frames F] [--iters I] [--model smpl|smplx]
 
-One "step" = one pass of the hot path over one batch of F synthetic frames per GPU:
-the fused fit kernel (all Adam iterations), the final LBS forward (joints + 6890
-vertices per frame) and, for N > 1, the all-gather of the fitted parameters over
-RCCL.  Frames shard across ranks with no data-path collective (weak scaling: F frames
-per GPU).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line; see DESIGN.md "Measurement" for the definitions of `roofline` and
-`cpu_baseline`.
+Default workload = the north-star headline: ONE synthetic AMASS sequence of T = 4096 frames whose
+frames shard over the N ranks in contiguous blocks (``parallel.shard_bounds``; strong scaling: the
+total work is fixed, N = 1 fits all 4096 frames on one GPU).  ``--frames F`` switches to weak scaling
+(F frames per GPU).  One "step" = one pass of the hot path over the rank's frames: the fused fit
+kernel (all Adam iterations), the final LBS forward (joints + all vertices per frame) and, for N > 1,
+the all-gather of the fitted parameters over RCCL (enqueued behind the fit, waited for after the LBS
+launches).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; the
+1024-frames-per-GPU figure of BASELINE configs[1] rides along under ``weak_1024`` (measured in the
+same process after the timed region).  See DESIGN.md "Measurement" for `roofline` / `cpu_baseline`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -28,11 +31,24 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 # algorithmic work per unit (SURVEY.md §8d / DESIGN.md)
-FIT_FLOP_PER_FRAME_ITER = 0.11e6        # analytic forward + backward + Adam, GMM prior dominates
-LBS_BYTES_PER_FRAME = 83_560            # 340 B params in + 540 B joints + 82 680 B vertices out
-LBS_FLOP_PER_FRAME = 13.1e6
+FIT_FLOP_PER_FRAME_ITER = {"smpl": 0.11e6, "smplx": 0.13e6}   # analytic forward + backward + Adam, GMM prior dominates
 FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 HBM_PEAK_GBS = 8000.0
+ROUND = "r02"
+
+
+def lbs_bytes_per_frame(model) -> int:
+    """params in + joints out + vertices out (SMPL: 340 + 540 + 82 680 = 83 560 B)."""
+    n = model.native
+    p = 4 * (3 + 3 * (n.num_joints - 1) + n.num_betas + 3)
+    return p + 12 * (n.num_joints + n.num_extra) + 12 * n.num_vertices
+
+
+def lbs_flop_per_frame(model) -> float:
+    """fp32-equivalent flops of the two LBS contractions + skinning (SMPL: 13.1 MFLOP)."""
+    n = model.native
+    V, J = n.num_vertices, n.num_joints
+    return 2.0 * V * 3 * (9 * (J - 1) + n.num_betas) + 2.0 * V * 12 * J + 2.0 * V * 12
 
 
 def parse():
@@ -40,38 +56,53 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU (BASELINE configs[1]: 1024)")
+    ap.add_argument("--total-frames", type=int, default=4096,
+                    help="frames of the ONE sequence sharded over all ranks (strong scaling; north-star: 4096)")
+    ap.add_argument("--frames", type=int, default=None,
+                    help="weak scaling instead: this many frames per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--iters", type=int, default=100, help="Adam iterations per frame")
+    ap.add_argument("--model", choices=("smpl", "smplx"), default="smpl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline's B=1 loop")
+    ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1024-frames-per-GPU measurement")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed B=1 fits per thread setting of the CPU baseline")
     return ap.parse_args()
 
 
-def build_problem(frames, seed, device):
-    """Synthetic model, prior, targets and initialisation, all resident on `device`."""
+def build_problem(total_frames, start, stop, seed, device, model_kind="smpl"):
+    """Synthetic model, prior and the frames [start, stop) of the `total_frames`-frame sequence `seed`."""
     from keypoints2body_amd import synthetic
-    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter, guess_init_transl_from_root
+    from keypoints2body_amd.core.fitters.world_space import guess_init_transl_from_root
     from keypoints2body_amd.models.body_model import BodyModel
     from keypoints2body_amd.models.smpl_data import SMPLData
     from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
 
+    if model_kind != "smpl":
+        from keypoints2body_amd import smplx_bench
+        return smplx_bench.build_problem(total_frames, start, stop, seed, device)
     model = BodyModel.synthetic(seed=0, device=device)
     gmm = synthetic.make_gmm(seed=0)
     prior = MaxMixturePrior(MixtureBuffers.from_mixture(gmm.means, gmm.covars, gmm.weights), device=device)
-    poses = synthetic.make_poses(frames, seed=seed)
-    dev = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device).contiguous()
-    gt = model(global_orient=dev(poses.global_orient), body_pose=dev(poses.body_pose), betas=dev(poses.betas),
-               transl=dev(poses.transl), return_verts=False)
-    j3d = gt.joints[:, :22].contiguous()
-    zeros = lambda c: torch.zeros((frames, c), dtype=torch.float32, device=device)
-    transl0 = guess_init_transl_from_root(model, zeros(72), zeros(10), j3d, joints_category="AMASS")
+    poses = synthetic.make_poses(total_frames, seed=seed)
+    n = stop - start
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a[start:stop]), dtype=torch.float32, device=device).contiguous()
+    zeros = lambda c: torch.zeros((n, c), dtype=torch.float32, device=device)
+    if n == 0:
+        j3d = torch.zeros((0, 22, 3), dtype=torch.float32, device=device)
+        transl0 = zeros(3)
+    else:
+        gt = model(global_orient=dev(poses.global_orient), body_pose=dev(poses.body_pose), betas=dev(poses.betas),
+                   transl=dev(poses.transl), return_verts=False)
+        j3d = gt.joints[:, :22].contiguous()
+        transl0 = guess_init_transl_from_root(model, zeros(72), zeros(10), j3d, joints_category="AMASS")
     init = SMPLData(betas=zeros(10), global_orient=zeros(3), body_pose=zeros(69), transl=transl0.contiguous())
-    return model, prior, j3d, init, poses
+    return model, prior, j3d, init
 
 
-def cpu_baseline(iters, n_loop_frames):
-    """Reference-style CPU loop (oracle port) on this host's cores: per-frame B=1
-    fits, exactly what `optimize_params_frame` does per frame, plus one batched call."""
+def cpu_baseline(iters, runs):
+    """Reference-style CPU loop (oracle port of world_space.py:248-256: full SMPL forward incl. all vertices every
+    iteration, torch autograd, torch.optim.Adam) on this host's cores.  Per-frame B=1 fits exactly as
+    `optimize_params_frame` does them: one warm-up fit, then the MEDIAN of `runs` timed fits, with all the cores
+    this process may use and again with ONE thread; plus the best batched figure (B=32, median of 3)."""
     from keypoints2body_amd import synthetic
     from oracle.fit_torch import GMMPrior, fit_world_adam, guess_init_transl
     from oracle.smpl_torch import TorchSMPL
@@ -82,12 +113,11 @@ def cpu_baseline(iters, n_loop_frames):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))
-    torch.set_num_threads(cores)
     model = TorchSMPL(synthetic.make_body_model(0))
     g = synthetic.make_gmm(0)
     prior = GMMPrior(g.means, g.covars, g.weights)
     nb = 32
-    poses = synthetic.make_poses(max(n_loop_frames, nb), seed=1000)
+    poses = synthetic.make_poses(max(runs + 1, nb), seed=1000)
     t = lambda a: torch.tensor(a)
     with torch.no_grad():
         j3d = model(global_orient=t(poses.global_orient), body_pose=t(poses.body_pose), betas=t(poses.betas),
@@ -98,26 +128,49 @@ def cpu_baseline(iters, n_loop_frames):
 
     def fit(sl):
         n = j3d[sl].shape[0]
-        return fit_world_adam(model, prior, z(n, 3), z(n, 69), z(n, 10), tr0[sl], j3d[sl], None, num_iters=iters)
+        t0 = time.perf_counter()
+        fit_world_adam(model, prior, z(n, 3), z(n, 69), z(n, 10), tr0[sl], j3d[sl], None, num_iters=iters)
+        return time.perf_counter() - t0
 
-    fit(slice(0, 1))                                     # warm-up
-    t0 = time.perf_counter()
-    for i in range(n_loop_frames):
-        fit(slice(i, i + 1))
-    loop_s = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    def loop(threads):
+        torch.set_num_threads(threads)
+        fit(slice(0, 1))                                     # warm-up
+        return statistics.median(fit(slice(1 + i, 2 + i)) for i in range(runs))
+
+    t_all = loop(cores)
+    t_one = loop(1)
+    torch.set_num_threads(cores)
     fit(slice(0, nb))
-    batch_s = time.perf_counter() - t0
+    t_batch = statistics.median(fit(slice(0, nb)) for _ in range(3))
     return {
-        "value": round(n_loop_frames / loop_s, 3),
+        "value": round(1.0 / t_all, 3),
         "unit": "frames/s",
-        "cores": torch.get_num_threads(),
+        "cores": cores,
         "kind": "port",
-        "sample": (f"{n_loop_frames} frames fitted one at a time (B=1, {iters} Adam iters, full SMPL forward incl. 6890 "
-                   f"vertices every iteration, torch autograd + torch.optim.Adam) in {loop_s:.2f}s; one batched "
-                   f"B={nb} call: {nb / batch_s:.2f} frames/s"),
-        "batched_value": round(nb / batch_s, 3),
+        "sample": (f"B=1 fits ({iters} Adam iters, full SMPL forward incl. 6890 vertices every iteration, torch autograd + "
+                   f"torch.optim.Adam), 1 warm-up + median of {runs} timed fits: {t_all:.3f} s/frame on {cores} threads, "
+                   f"{t_one:.3f} s/frame on 1 thread; one batched B={nb} call (median of 3): {nb / t_batch:.2f} frames/s"),
+        "value_1thread": round(1.0 / t_one, 3),
+        "batched_value": round(nb / t_batch, 3),
     }
+
+
+def read_traffic(model_kind, frames):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md); only known for the
+    frame counts that were profiled."""
+    for name in (f"traffic_{ROUND}.json", "traffic_r01.json"):
+        tfile = REPO / "profiles" / name
+        if not tfile.exists():
+            continue
+        try:
+            tj = json.loads(tfile.read_text())
+        except Exception:
+            continue
+        pre = "" if model_kind == "smpl" else model_kind + "_"
+        fit, lbs = tj.get(f"{pre}fit_frames_{frames}"), tj.get(f"{pre}lbs_frames_{frames}")
+        if fit is not None or lbs is not None:
+            return fit, lbs, name
+    return None, None, None
 
 
 def main():
@@ -144,105 +197,143 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+    from keypoints2body_amd import native
     from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
-    from keypoints2body_amd.parallel import gather_fit_outputs
-
-    F = args.frames
-    model, prior, j3d, init, _ = build_problem(F, seed=1000 + rank, device=device)
-    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=args.iters, num_iters_followup=args.iters,
-                              use_lbfgs=False, joints_category="AMASS", device=device, pose_prior=prior)
+    from keypoints2body_amd.parallel import gather_fit_outputs, shard_bounds
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    fit_ms, lbs_ms = [], []
 
-    def step(record=False):
-        from keypoints2body_amd import native
-        e0, e1, e2 = ev(), ev(), ev()
-        e0.record()
+    def measure(total, weak, steps, warmup):
+        """Time `steps` passes over this rank's share of `total` frames (weak: `total` = frames per GPU)."""
+        if weak:
+            T, start, stop, per = total * world, rank * total, (rank + 1) * total, total
+        else:
+            T = total
+            start, stop = shard_bounds(T, world, rank)
+            per = (T + world - 1) // world
+        model, prior, j3d, init = build_problem(T, start, stop, 1000, device, args.model)
+        fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=args.iters, num_iters_followup=args.iters,
+                                  use_lbfgs=False, joints_category="AMASS", device=device, pose_prior=prior)
         cfg = fitter._config(0, 600.0, 5.0, False, False)
-        out = native.fit_world(model.native, prior.native, cfg, list(range(22)), j3d, None, init.global_orient,
-                               init.body_pose, init.betas, init.transl)
-        e1.record()
-        # the parameter exchange is enqueued behind the fit and runs on RCCL's stream under the LBS launches
-        gathered, work = gather_fit_outputs(out, dist, async_op=True) if dist is not None else (None, None)
-        joints, verts = model.native.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"])
-        e2.record()
-        if work is not None:
-            work.wait()
-        if record:
-            fit_ms.append((e0, e1))
-            lbs_ms.append((e1, e2))
-        return out, joints, verts, gathered
+        fit_ev, lbs_ev = [], []
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, joints, verts, gathered = step(record=True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        def step(record=False):
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            out = fitter.fit_params(cfg, j3d, init)
+            e1.record()
+            # the parameter exchange is enqueued behind the fit and runs on RCCL's stream under the LBS launches
+            gathered, work = gather_fit_outputs(out, dist, pad_to=per, async_op=True) if dist is not None else (None, None)
+            joints, verts = fitter.final_forward(out)
+            e2.record()
+            if work is not None:
+                work.wait()
+            if record:
+                fit_ev.append((e0, e1))
+                lbs_ev.append((e1, e2))
+            return out, joints, verts, gathered
 
-    fit_avg = float(np.mean([a.elapsed_time(b) for a, b in fit_ms]))      # ms, HIP events on the launch stream
-    lbs_avg = float(np.mean([a.elapsed_time(b) for a, b in lbs_ms]))
-    err_cm = float((joints[:, :22] - j3d).norm(dim=-1).mean().item() * 100)
+        for _ in range(warmup):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, joints, verts, gathered = step(record=True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        n_local = stop - start
+        res = {
+            "T": T, "frames_local": n_local, "elapsed": elapsed, "model": model,
+            "fit_ms": float(np.mean([a.elapsed_time(b) for a, b in fit_ev])),      # HIP events on the launch stream
+            "lbs_ms": float(np.mean([a.elapsed_time(b) for a, b in lbs_ev])),
+            "err_cm": float((joints[:, :22] - j3d).norm(dim=-1).mean().item() * 100) if n_local else 0.0,
+            "loss": float(out["loss"].mean()) if n_local else 0.0,
+        }
+        return res
+
+    weak = args.frames is not None
+    main_res = measure(args.frames if weak else args.total_frames, weak, args.steps, args.warmup)
+    weak_res = None
+    if not weak and not args.no_weak_line:
+        weak_res = measure(1024, True, args.steps, args.warmup)
 
     if rank == 0:
-        total_frames = F * world * args.steps
-        ms_per_step = elapsed / args.steps * 1e3
-        fit_tflops = FIT_FLOP_PER_FRAME_ITER * args.iters * F / (fit_avg * 1e-3) / 1e12
-        lbs_gbs = LBS_BYTES_PER_FRAME * F / (lbs_avg * 1e-3) / 1e9
-        # HBM bytes per launch measured with rocprofv3 PMC passes (profiles/README.md); only known for
-        # the frame counts that were profiled
-        traffic = traffic_lbs = None
-        tfile = REPO / "profiles" / "traffic_r01.json"
-        if tfile.exists():
-            try:
-                tj = json.loads(tfile.read_text())
-                traffic, traffic_lbs = tj.get(f"fit_frames_{F}"), tj.get(f"lbs_frames_{F}")
-            except Exception:
-                pass
+        r = main_res
+        model = r["model"]
+        F = r["frames_local"]
+        ms_per_step = r["elapsed"] / args.steps * 1e3
+        flop_iter = FIT_FLOP_PER_FRAME_ITER[args.model]
+        lbs_bytes = lbs_bytes_per_frame(model)
+        fit_tflops = flop_iter * args.iters * F / (r["fit_ms"] * 1e-3) / 1e12
+        lbs_gbs = lbs_bytes * F / (r["lbs_ms"] * 1e-3) / 1e9
+        traffic, traffic_lbs, traffic_src = read_traffic(args.model, F)
+        n = model.native
+        shape = (f"{'SMPL' if args.model == 'smpl' else 'SMPL-X'}-shaped model (V={n.num_vertices}, J={n.num_joints}, "
+                 f"{n.num_betas} betas)")
+        if weak:
+            workload = (f"{args.frames} synthetic 22-joint AMASS frames per GPU, {shape}, {args.iters} Adam iters, "
+                        "world mode, final joints+vertices produced")
+        else:
+            workload = (f"{r['T']}-frame sequence of synthetic 22-joint AMASS frames sharded over {world} GPU(s) "
+                        f"({F} frames on rank 0), {shape}, {args.iters} Adam iters, world mode, final joints+vertices produced")
         line = {
             "metric": "SMPL frames fitted/sec (100 Adam iters, 22-joint AMASS)",
-            "value": round(total_frames / elapsed, 1),
+            "value": round(r["T"] * args.steps / r["elapsed"], 1),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{F} synthetic 22-joint AMASS frames per GPU, SMPL-shaped model (V=6890, J=24, 10 betas), "
-                            f"{args.iters} Adam iters, world mode, final joints+vertices produced",
-                "frames_per_gpu": F, "adam_iters": args.iters, "parallelism": f"frames sharded x{world}",
+                "workload": workload,
+                "total_frames": r["T"], "frames_rank0": F, "adam_iters": args.iters,
+                "parallelism": f"frames sharded x{world}",
             },
+            # dominant kernel: the fused fit.  It never touches HBM inside its loop; its bound is fp32 vector-ALU issue
+            # (DESIGN §4.1), so the peak is the fp32 VALU peak (= the fp32-input MFMA peak), not an f16 matrix peak.
             "roofline": {
-                "kernel": "k2b_fit_world_kernel", "bound": "mfma", "achieved": round(fit_tflops, 3),
+                "kernel": "k2b_fit_world_kernel", "bound": "valu", "achieved": round(fit_tflops, 3),
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fit_tflops / FP32_PEAK_TFLOPS, 4),
-                "traffic": traffic, "avg_launch_ms": round(fit_avg, 4),
+                "traffic": traffic, "avg_launch_ms": round(r["fit_ms"], 4),
+                "note": "algorithmic fp32 flops (0.11 MFLOP per frame-iteration) against the fp32 vector peak",
             },
             "roofline_lbs": {
                 "kernel": "k2b_pose_setup_kernel+k2b_lbs_mfma_kernel+k2b_gather_joints_kernel", "bound": "hbm",
                 "achieved": round(lbs_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(lbs_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_lbs, "avg_launch_ms": round(lbs_avg, 4),
-                "achieved_tflops": round(LBS_FLOP_PER_FRAME * F / (lbs_avg * 1e-3) / 1e12, 2),
+                "frac": round(lbs_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_lbs, "avg_launch_ms": round(r["lbs_ms"], 4),
+                "bytes_per_frame": lbs_bytes,
+                "achieved_tflops": round(lbs_flop_per_frame(model) * F / (r["lbs_ms"] * 1e-3) / 1e12, 2),
             },
-            "quality": {"mean_joint_error_cm": round(err_cm, 3), "mean_final_loss": round(float(out["loss"].mean()), 2)},
+            "quality": {"mean_joint_error_cm": round(r["err_cm"], 3), "mean_final_loss": round(r["loss"], 2)},
         }
+        if traffic_src:
+            line["roofline"]["traffic_source"] = line["roofline_lbs"]["traffic_source"] = "profiles/" + traffic_src
+        if weak_res is not None:
+            w = weak_res
+            line["weak_1024"] = {
+                "workload": "BASELINE configs[1]: 1024 frames per GPU (weak scaling), same model and settings",
+                "value": round(w["T"] * args.steps / w["elapsed"], 1), "unit": "frames/s",
+                "ms_per_step": round(w["elapsed"] / args.steps * 1e3, 4),
+                "fit_ms": round(w["fit_ms"], 4), "lbs_ms": round(w["lbs_ms"], 4),
+                "fit_frac_fp32": round(flop_iter * args.iters * w["frames_local"] / (w["fit_ms"] * 1e-3) / 1e12
+                                       / FP32_PEAK_TFLOPS, 4),
+                "lbs_frac_hbm": round(lbs_bytes * w["frames_local"] / (w["lbs_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_frames)
+            line["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_runs)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

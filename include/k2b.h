@@ -14,7 +14,13 @@
  *     contiguous float32 tensor on the HIP device; "host" pointers are host memory;
  *   - all matrices are row-major (C order), float32 unless stated;
  *   - launches are stream-ordered on `stream` (a hipStream_t passed as void*; NULL =
- *     the default stream); no call synchronises the device except *_create;
+ *     the default stream).  Calls that may block the host or synchronise the device:
+ *     *_create / *_destroy always; k2b_lbs when its per-model workspace has to GROW (first
+ *     call, or more frames than any earlier call: hipDeviceSynchronize + hipFree/hipMalloc;
+ *     k2b_model_reserve() pre-sizes it so that later calls never do); k2b_fit_world on the
+ *     FIRST use of an (iterations, lr, beta1, beta2) combination per model (blocking upload
+ *     of the Adam bias table; at most 64 tables are kept, least recently used evicted after
+ *     a stream sync); k2b_vertex_term when the joint selection changes (stream sync + copy);
  *   - buffers are caller-owned; inputs are never written; handles may be shared by
  *     threads as long as concurrent calls use different streams AND different
  *     workspaces (one workspace per handle: serialise calls on one handle).
@@ -65,6 +71,9 @@ void k2b_model_destroy(k2b_model *model);
 /* Sizes: V, J, NB, E. */
 int k2b_model_dims(const k2b_model *model, int32_t *num_vertices, int32_t *num_joints,
                    int32_t *num_betas, int32_t *num_extra_joints);
+/* Pre-sizes the per-model LBS workspace for batches of up to `max_frames` frames, so that no later k2b_lbs
+ * call on this model allocates or synchronises (see Conventions).  Synchronises the device if it has to grow. */
+int k2b_model_reserve(k2b_model *model, int32_t max_frames);
 /* Copies the precomputed J_template [J][3] and J_dirs [J][3][NB] to HOST buffers (either may be NULL). */
 int k2b_model_joint_basis(const k2b_model *model, float *j_template, float *j_dirs);
 
@@ -111,6 +120,10 @@ typedef struct k2b_fit_config {
      * (losses.py:70-93: depth_loss_weight 100; its broadcast over the 4 torso joints makes the
      * effective weight 200 in that path).  0 = off. */
     float transl_prior_weight;
+    /* Debug / test knob: 0 = the launcher picks the launch shape from the batch size (the product setting);
+     * 1, 2, 3 force the split / split-paired / paired shape of the fused kernel (and a single launch), so that
+     * the parity tests can drive every shape with small cases.  Results do not depend on it. */
+    int32_t debug_launch_shape;
 } k2b_fit_config;
 
 void k2b_fit_config_default(k2b_fit_config *cfg);

@@ -9,7 +9,11 @@ Two execution modes, both with the reference's per-frame semantics:
 * ``use_previous_frame_init=False``: every frame starts from the same initial parameters, so
   the frames are independent and are fitted in TWO launches: frame 0
   (``num_iters_first``, no preserve term) and frames 1..T-1 as one batch
-  (``num_iters_followup``, preserve term towards the shared initial pose).
+  (``num_iters_followup``, preserve term towards the shared initial pose).  When a
+  ``torch.distributed`` process group is initialised (one process per GPU, ``torchrun``), that batch
+  is SHARDED over the ranks (``parallel.fit_frames_sharded``: contiguous blocks, no collective during
+  the iterations, one all-gather of the fitted parameters); every rank then runs the cheap final
+  forward over the whole sequence and returns the full, identical list of results.
 """
 from __future__ import annotations
 
@@ -24,6 +28,41 @@ from ..core.joints.adapters import normalize_sequence_observations
 from ..models.smpl_data import BodyModelFitResult, BodyModelParams, SMPLData
 from . import common
 from .frame import _with_root_aligned_transl
+
+
+def _process_group():
+    """The ``torch.distributed`` module when this process is one rank of an initialised group of > 1, else None."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def _fit_independent_frames(est, prev: BodyModelParams, xyz, conf, model_indices, dist):
+    """Frames that all start from `prev` (seq_ind >= 1 semantics), fitted in one batched launch or, under a
+    process group, in one launch per rank over its contiguous block + ONE all-gather of the parameters
+    (reference seam: the frame loop of ``api/sequence.py:214-281`` with ``use_previous_frame_init=False``)."""
+    n = xyz.shape[0]
+    if dist is None:
+        return est.fit_batch(_repeat_params(prev, n), xyz, conf, seq_ind=1, target_model_indices=model_indices,
+                             per_frame_conf=True)
+    from ..parallel import fit_frames_sharded
+    pose_dim, num_betas = int(prev.body_pose.shape[-1]), int(prev.betas.shape[-1])
+    device = xyz.device
+
+    def fit_block(sl: slice):
+        b = sl.stop - sl.start
+        if b <= 0:
+            e = lambda c: torch.zeros((0, c), dtype=torch.float32, device=device)
+            return {"global_orient": e(3), "body_pose": e(pose_dim), "betas": e(num_betas), "transl": e(3),
+                    "loss": torch.zeros((0,), dtype=torch.float32, device=device)}
+        out, _, _, _ = est.fit_batch(_repeat_params(prev, b), xyz[sl], conf[sl], seq_ind=1,
+                                     target_model_indices=model_indices, per_frame_conf=True, run_forward=False)
+        return out
+
+    out = fit_frames_sharded(fit_block, n, num_betas, pose_dim, dist)
+    joints, verts = est.fitter.final_forward(out)        # every rank: whole sequence, identical bits
+    return out, joints, verts, out["loss"]
 
 
 def _repeat_params(p: BodyModelParams, n: int) -> SMPLData:
@@ -98,8 +137,7 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
             results.append(engine.fit_frame(init_params=prev, j3d=xyz[idx: idx + 1], conf_3d=conf[idx], seq_ind=idx,
                                             target_model_indices=model_indices))
         return results
-    out, joints, verts, loss = est.fit_batch(_repeat_params(prev, T - 1), xyz[1:], conf[1:], seq_ind=1,
-                                             target_model_indices=model_indices, per_frame_conf=True)
+    out, joints, verts, loss = _fit_independent_frames(est, prev, xyz[1:], conf[1:], model_indices, _process_group())
     for i in range(T - 1):
         sl = slice(i, i + 1)
         results.append(BodyModelFitResult(

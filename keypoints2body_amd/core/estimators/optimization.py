@@ -53,7 +53,8 @@ class OptimizationEstimator:
         return self._fitter.fit_frame(init_params=init_params, j3d=j3d, conf_3d=conf_3d, seq_ind=seq_ind,
                                       target_model_indices=target_model_indices, **self._weights())
 
-    def fit_batch(self, init_params, j3d, conf_3d, seq_ind, target_model_indices=None, per_frame_conf=False):
+    def fit_batch(self, init_params, j3d, conf_3d, seq_ind, target_model_indices=None, per_frame_conf=False,
+                  run_forward=True):
         """B independent frames in one launch (not part of the reference protocol)."""
         return self._fitter.fit_batch(init_params, j3d, conf_3d, seq_ind, target_model_indices,
-                                      per_frame_conf=per_frame_conf, **self._weights())
+                                      per_frame_conf=per_frame_conf, run_forward=run_forward, **self._weights())

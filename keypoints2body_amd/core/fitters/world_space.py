@@ -12,7 +12,10 @@ one ``k2b_lbs`` call for the final vertices/joints (``world_space.py:258-278``).
 ``torch.optim.LBFGS`` (strong Wolfe) as the outer algorithm, exactly as the reference does, but its
 closure no longer builds an autograd graph: loss and gradient of every evaluation come from an
 evaluate-only launch of the same kernel (``step_size = 0``, ``grad_out``).  L-BFGS couples all
-parameters it is given, so frames are fitted one at a time in that mode, like the reference.
+parameters it is given: the reference hands ONE optimiser the parameters of the whole batch, so for
+B > 1 its frames share a line search (a batch is then NOT B independent fits); the API only ever
+calls it with B = 1 (``api/sequence.py:215``).  This class runs one L-BFGS per frame, which equals
+the reference for B = 1 and deliberately differs (independent frames) for B > 1.
 
 Differences, all deliberate and documented in DESIGN.md:
 
@@ -155,10 +158,12 @@ class WorldSpaceFitter:
 
     def fit_batch(self, init_params: SMPLData, j3d, conf_3d=None, seq_ind: int = 0, target_model_indices=None,
                   joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = False,
-                  per_frame_conf: bool = False, want_vertices: bool = True):
+                  per_frame_conf: bool = False, want_vertices: bool = True, run_forward: bool = True):
         """Fit B independent frames in one launch.
 
-        Returns ``(params: dict of (B,.) tensors, joints, vertices, per_frame_loss)``.
+        Returns ``(params: dict of (B,.) tensors, joints, vertices, per_frame_loss)``; with
+        ``run_forward=False`` the final forward is left to the caller (``final_forward``) and joints / vertices
+        are ``None`` - the sharded sequence path gathers the parameters first.
         """
         if init_params.transl is None:
             raise ValueError("init_params.transl must be provided")
@@ -206,9 +211,22 @@ class WorldSpaceFitter:
             out = self._fit_lbfgs(cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas)
         else:
             out = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, go, bp, be, tr)
-        joints, verts = self.smpl.native.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"],
-                                             want_vertices=want_vertices)
+        if not run_forward:
+            return out, None, None, out["loss"]
+        joints, verts = self.final_forward(out, want_vertices=want_vertices)
         return out, joints, verts, out["loss"]
+
+    def fit_params(self, cfg, targets, init):
+        """The hot call alone: ONE fused-fit launch on device tensors that are already in kernel layout
+        (`targets` (B,K,3) in the order of this fitter's joint category, `init` on the device).  `bench.py` times
+        this + `final_forward`; `fit_batch` is the same two calls behind the reference's argument handling."""
+        return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, list(self.smpl_index), targets, None,
+                                init.global_orient, init.body_pose, init.betas, init.transl)
+
+    def final_forward(self, out, want_vertices=True):
+        """Final no-grad forward of the reference (world_space.py:258-278): joints (+ vertices) of fitted parameters."""
+        return self.smpl.native.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"],
+                                    want_vertices=want_vertices)
 
     def _split_targets(self, model_idx, tgt, conf):
         return split_targets(self.smpl, model_idx, tgt, conf)
@@ -221,7 +239,9 @@ class WorldSpaceFitter:
     def _fit_lbfgs(self, cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas):
         """LBFGS branch (world_space.py:231-247): ``torch.optim.LBFGS(params, max_iter=num_iters,
         lr=step_size, line_search_fn="strong_wolfe").step(closure)`` per frame, with the closure's
-        loss and gradient evaluated by the HIP kernel; final loss re-evaluated afterwards."""
+        loss and gradient evaluated by the HIP kernel; final loss re-evaluated afterwards.  One optimiser
+        per frame: identical to the reference for B = 1 (all its API ever passes); for B > 1 the reference
+        couples the frames in one line search, this does not (see the module docstring)."""
         max_iter = int(cfg.num_iters)
         cfg.num_iters, cfg.step_size = 1, 0.0          # evaluate-only launches
         B, D = go.shape[0], bp.shape[1]

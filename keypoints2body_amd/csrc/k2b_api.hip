@@ -81,8 +81,10 @@ struct k2b_model {
     // LBS per-frame operand workspace (grow-only)
     k2b::k2b_half *wsXh = nullptr, *wsXl = nullptr, *wsAh = nullptr, *wsAl = nullptr;
     int ws_bpad = 0;
-    // Adam coefficient tables, one per (iters, lr, b1, b2); never overwritten once built
-    std::map<std::tuple<int, double, double, double>, float2*> adam_tables;
+    // Adam coefficient tables, one per (iters, lr, b1, b2); at most kMaxAdamTables, least recently used evicted
+    struct AdamTable { float2* dev; uint64_t last_use; };
+    std::map<std::tuple<int, double, double, double>, AdamTable> adam_tables;
+    uint64_t adam_clock = 0;
     std::mutex mu;
 };
 
@@ -120,6 +122,7 @@ void k2b_fit_config_default(k2b_fit_config* c) {
     for (int i = 0; i < 4; ++i) { c->angle_prior_index[i] = idx[i]; c->angle_prior_sign[i] = sg[i]; }
     c->optimize_mask = 15;
     c->transl_prior_weight = 0.0f;
+    c->debug_launch_shape = 0;
 }
 
 int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t E, const float* v_template,
@@ -308,7 +311,7 @@ void k2b_model_destroy(k2b_model* m) {
     if (m->extra_ids) (void)hipFree(m->extra_ids);
     if (m->tree) (void)hipFree(m->tree);
     if (m->sel_ws) (void)hipFree(m->sel_ws);
-    for (auto& kv : m->adam_tables) (void)hipFree(kv.second);
+    for (auto& kv : m->adam_tables) (void)hipFree(kv.second.dev);
     delete m;
 }
 
@@ -487,10 +490,21 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
                 const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
                 h[t - 1] = make_float2((float)(lr / bc1), (float)std::sqrt(bc2));
             }
+            constexpr size_t kMaxAdamTables = 64;
+            if (model->adam_tables.size() >= kMaxAdamTables) {       // evict the least recently used table
+                auto victim = model->adam_tables.begin();
+                for (auto jt = model->adam_tables.begin(); jt != model->adam_tables.end(); ++jt)
+                    if (jt->second.last_use < victim->second.last_use) victim = jt;
+                HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // a launch in flight may still read it
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipFree(victim->second.dev));
+                model->adam_tables.erase(victim);
+            }
             HIP_TRY(upload(&coef, h.data(), h.size()));
-            model->adam_tables[key] = coef;
+            model->adam_tables[key] = {coef, ++model->adam_clock};
         } else {
-            coef = it->second;
+            coef = it->second.dev;
+            it->second.last_use = ++model->adam_clock;
         }
     }
 
@@ -526,9 +540,42 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     a.freeze_betas = cfg->freeze_betas ? 1 : 0;
     a.opt_mask = (cfg->optimize_mask & 15) & (cfg->freeze_betas ? ~4 : ~0);
     a.transl_prior_w = cfg->transl_prior_weight;
+    if (cfg->debug_launch_shape < 0 || cfg->debug_launch_shape > 3)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: debug_launch_shape=%d must be 0..3", cfg->debug_launch_shape);
+    a.force_shape = cfg->debug_launch_shape;
     a.num_cus = device_cus();
     HIP_TRY(k2b::launch_fit_world(a, (hipStream_t)stream));
     return K2B_OK;
+}
+
+namespace {
+// grow-only per-model workspace of the per-frame LBS operands (caller holds m->mu)
+int reserve_lbs_workspace(k2b_model* m, int bpad) {
+    if (bpad <= m->ws_bpad) return K2B_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    k2b::k2b_half** ws[] = {&m->wsXh, &m->wsXl, &m->wsAh, &m->wsAl};
+    for (auto w : ws) { if (*w) HIP_TRY(hipFree(*w)); *w = nullptr; }
+    m->ws_bpad = 0;
+    const size_t nx = (size_t)m->k_steps_x * bpad * 16, na = (size_t)12 * m->k_steps_a * bpad * 16;
+    HIP_TRY(hipMalloc((void**)&m->wsXh, nx * sizeof(k2b::k2b_half)));
+    HIP_TRY(hipMalloc((void**)&m->wsXl, nx * sizeof(k2b::k2b_half)));
+    HIP_TRY(hipMalloc((void**)&m->wsAh, na * sizeof(k2b::k2b_half)));
+    HIP_TRY(hipMalloc((void**)&m->wsAl, na * sizeof(k2b::k2b_half)));
+    // rows of padding frames are never written by the set-up kernel: keep them finite
+    HIP_TRY(hipMemset(m->wsXh, 0, nx * sizeof(k2b::k2b_half)));
+    HIP_TRY(hipMemset(m->wsXl, 0, nx * sizeof(k2b::k2b_half)));
+    HIP_TRY(hipMemset(m->wsAh, 0, na * sizeof(k2b::k2b_half)));
+    HIP_TRY(hipMemset(m->wsAl, 0, na * sizeof(k2b::k2b_half)));
+    m->ws_bpad = bpad;
+    return K2B_OK;
+}
+}  // namespace
+
+extern "C" int k2b_model_reserve(k2b_model* m, int32_t max_frames) {
+    if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_reserve: model is NULL");
+    if (max_frames < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_reserve: max_frames=%d", max_frames);
+    std::lock_guard<std::mutex> lk(m->mu);
+    return reserve_lbs_workspace(m, k2b::lbs_frames_padded(max_frames));
 }
 
 int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* bp, const float* be, const float* tr,
@@ -543,23 +590,7 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     const int bpad = k2b::lbs_frames_padded(B);
     {
         std::lock_guard<std::mutex> lk(m->mu);
-        if (bpad > m->ws_bpad) {
-            HIP_TRY(hipDeviceSynchronize());
-            k2b::k2b_half** ws[] = {&m->wsXh, &m->wsXl, &m->wsAh, &m->wsAl};
-            for (auto w : ws) { if (*w) HIP_TRY(hipFree(*w)); *w = nullptr; }
-            m->ws_bpad = 0;
-            const size_t nx = (size_t)m->k_steps_x * bpad * 16, na = (size_t)12 * m->k_steps_a * bpad * 16;
-            HIP_TRY(hipMalloc((void**)&m->wsXh, nx * sizeof(k2b::k2b_half)));
-            HIP_TRY(hipMalloc((void**)&m->wsXl, nx * sizeof(k2b::k2b_half)));
-            HIP_TRY(hipMalloc((void**)&m->wsAh, na * sizeof(k2b::k2b_half)));
-            HIP_TRY(hipMalloc((void**)&m->wsAl, na * sizeof(k2b::k2b_half)));
-            // rows of padding frames are never written by the set-up kernel: keep them finite
-            HIP_TRY(hipMemset(m->wsXh, 0, nx * sizeof(k2b::k2b_half)));
-            HIP_TRY(hipMemset(m->wsXl, 0, nx * sizeof(k2b::k2b_half)));
-            HIP_TRY(hipMemset(m->wsAh, 0, na * sizeof(k2b::k2b_half)));
-            HIP_TRY(hipMemset(m->wsAl, 0, na * sizeof(k2b::k2b_half)));
-            m->ws_bpad = bpad;
-        }
+        if (const int rc = reserve_lbs_workspace(m, bpad); rc != K2B_OK) return rc;
     }
     k2b::PoseArgs pa{};
     pa.j_template = m->j_template; pa.j_dirs = m->j_dirs; pa.parents = m->parents;

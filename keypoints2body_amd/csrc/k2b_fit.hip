@@ -907,7 +907,7 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     // 2.4 rounds, paid as 3).  Launch the whole rounds first and the remainder on its own, in the shape that suits
     // ITS size (1 808 frames: split-paired, 0.6 of a paired round).  Frames are independent: results do not change.
     const int full = MAXS * a_in.num_cus;
-    if (a_in.num_frames > full && a_in.num_frames % full != 0 && !getenv("K2B_FIT_MODE")) {
+    if (a_in.num_frames > full && a_in.num_frames % full != 0 && !a_in.force_shape) {
         const int head = (a_in.num_frames / full) * full;
         const hipError_t e = launch_fit_world(frame_range(a_in, 0, head), stream);
         if (e != hipSuccess) return e;
@@ -919,12 +919,10 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     // beyond: two frames per wave.
     int fpw = (a.num_frames + a.num_cus - 1) / a.num_cus;
     int mode = fpw <= 4 ? MODE_SPLIT : (fpw <= MAXW ? MODE_SPLIT_PAIRED : MODE_PAIRED);
-    // test hook: K2B_FIT_MODE=split|split_paired|paired forces a shape regardless of the batch size, so that
-    // the parity tests can drive every shape with the small golden cases
-    if (const char* force = getenv("K2B_FIT_MODE")) {
-        if (!strcmp(force, "split")) mode = MODE_SPLIT;
-        else if (!strcmp(force, "split_paired")) mode = MODE_SPLIT_PAIRED;
-        else if (!strcmp(force, "paired")) mode = MODE_PAIRED;
+    // k2b_fit_config::debug_launch_shape forces a shape regardless of the batch size, so that the parity tests can
+    // drive every shape with the small golden cases
+    if (a.force_shape) {
+        mode = a.force_shape == 1 ? MODE_SPLIT : (a.force_shape == 2 ? MODE_SPLIT_PAIRED : MODE_PAIRED);
         fpw = mode == MODE_SPLIT ? 4 : (mode == MODE_PAIRED ? MAXS : MAXW);
         if (fpw > a.num_frames) fpw = a.num_frames;
     }

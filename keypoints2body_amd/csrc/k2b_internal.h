@@ -58,6 +58,7 @@ struct FitArgs {
     int angle_index[4];
     float angle_sign[4];
     int num_cus;
+    int force_shape;            // 0 = chosen by the batch size; 1..3 = split / split-paired / paired (k2b_fit_config::debug_launch_shape)
 };
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);

@@ -25,7 +25,7 @@ K2B_ERR_NO_DEVICE = -4
 
 EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
-    "k2b_model_joint_basis", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
+    "k2b_model_joint_basis", "k2b_model_reserve", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
     "k2b_fit_world", "k2b_lbs", "k2b_vertex_term", "k2b_adam_step", "k2b_angular_error_deg",
 )
 
@@ -51,6 +51,7 @@ class FitConfigC(C.Structure):
         ("angle_prior_sign", C.c_float * 4),
         ("optimize_mask", C.c_int32),
         ("transl_prior_weight", C.c_float),
+        ("debug_launch_shape", C.c_int32),
     ]
 
 
@@ -80,6 +81,8 @@ def load_library():
     lib.k2b_model_destroy.argtypes = [vp]
     lib.k2b_model_dims.restype = C.c_int
     lib.k2b_model_dims.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
+    lib.k2b_model_reserve.restype = C.c_int
+    lib.k2b_model_reserve.argtypes = [vp, C.c_int32]
     lib.k2b_model_joint_basis.restype = C.c_int
     lib.k2b_model_joint_basis.argtypes = [vp, fp, fp]
     lib.k2b_prior_create.restype = C.c_int
@@ -188,6 +191,11 @@ class NativeModel:
     @property
     def handle(self):
         return self._h
+
+    def reserve(self, max_frames: int) -> None:
+        """Pre-size the LBS workspace: no later ``lbs`` call of up to `max_frames` frames allocates or synchronises."""
+        with torch.cuda.device(self.device):
+            _check(load_library().k2b_model_reserve(self._h, int(max_frames)), "k2b_model_reserve")
 
     def joint_basis(self):
         jt = np.zeros((self.num_joints, 3), np.float32)

@@ -9,15 +9,47 @@ fit kernel (``csrc/k2b_fit.hip``), not here.
 """
 from __future__ import annotations
 
+import io
 import os
 import pickle
-import sys
 from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
 
 from . import native
+
+
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """Unpickler for the reference's ``gmm_XX.pkl`` (a dict of numpy arrays, protocol 2, written by Python 2):
+    only the globals numpy's own array pickling needs are resolvable, so loading the file cannot run code.
+    sklearn ``GMM`` objects (the reference's second accepted form, prior.py:140-143) are refused: unpickling one
+    means importing and executing arbitrary classes named by the file."""
+
+    _ALLOWED = {
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy", "ndarray"), ("numpy", "dtype"),
+        ("_codecs", "encode"),      # how Python 3 writes an array's bytes into a protocol-2 pickle (a pure str -> bytes function)
+    }
+
+    def find_class(self, module, name):
+        if (module, name) == ("_codecs", "encode"):
+            import codecs
+            return codecs.encode
+        if (module, name) in self._ALLOWED:
+            import numpy.core.multiarray as _ma     # numpy 1.x and 2.x both resolve this path
+            if name in ("_reconstruct", "scalar"):
+                return getattr(_ma, name)
+            return getattr(np, name)
+        raise pickle.UnpicklingError(
+            f"mixture prior file names the global {module}.{name}; only plain dicts of numpy arrays are loaded "
+            "(convert other formats to an .npz with means / covars / weights)")
+
+
+def _load_mixture_pickle(path: str):
+    with open(path, "rb") as f:
+        return _ArraysOnlyUnpickler(io.BytesIO(f.read()), encoding="latin1").load()
 
 
 @dataclass
@@ -46,23 +78,25 @@ class MixtureBuffers:
 
     @classmethod
     def from_file(cls, path: str) -> "MixtureBuffers":
-        """Load a user-supplied mixture: ``.npz`` (means/covars/weights) or the
-        reference's ``gmm_XX.pkl`` dict / sklearn object (prior.py:133-146)."""
+        """Load a user-supplied mixture: ``.npz`` (means/covars/weights) or the reference's ``gmm_XX.pkl``
+        dict of arrays (prior.py:133-139), read with an unpickler that resolves numpy array globals only.
+
+        Deliberate differences from the reference: a missing file raises ``FileNotFoundError`` and an
+        unsupported content ``ValueError`` where the reference prints and calls ``sys.exit(-1)``
+        (prior.py:116-118,126-131,144-146) - a library must not end its host process - and pickled
+        sklearn ``GMM`` objects (prior.py:140-143) are refused instead of executed."""
         if not os.path.exists(path):
-            # the reference prints and calls sys.exit(-1) here (prior.py:126-131)
-            print(f'The path to the mixture prior "{path}" does not exist, exiting!')
-            sys.exit(-1)
+            raise FileNotFoundError(f'The path to the mixture prior "{path}" does not exist')
         if path.endswith(".npz"):
             with np.load(path) as z:
                 return cls.from_mixture(z["means"], z["covars"], z["weights"])
-        with open(path, "rb") as f:
-            gmm = pickle.load(f, encoding="latin1")
-        if isinstance(gmm, dict):
+        try:
+            gmm = _load_mixture_pickle(path)
+        except pickle.UnpicklingError as e:
+            raise ValueError(f"cannot load the mixture prior {path}: {e}") from e
+        if isinstance(gmm, dict) and all(k in gmm for k in ("means", "covars", "weights")):
             return cls.from_mixture(gmm["means"], gmm["covars"], gmm["weights"])
-        if "sklearn.mixture.gmm.GMM" in str(type(gmm)):
-            return cls.from_mixture(gmm.means_, gmm.covars_, gmm.weights_)
-        print(f"Unknown type for the prior: {type(gmm)}, exiting!")
-        sys.exit(-1)
+        raise ValueError(f"Unknown content for the prior {path}: {type(gmm)} (expected a dict with means / covars / weights)")
 
 
 class MaxMixturePrior:

@@ -76,10 +76,14 @@ def cuda(x):
     return torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda().contiguous()
 
 
-def native_fit(d, num_iters=None, want_grad=False, rows=None):
-    """Run the HIP fit on the inputs of golden case ``d``."""
+LAUNCH_SHAPES = {"auto": 0, "split": 1, "split_paired": 2, "paired": 3}     # k2b_fit_config.debug_launch_shape
+
+
+def native_fit(d, num_iters=None, want_grad=False, rows=None, shape="auto"):
+    """Run the HIP fit on the inputs of golden case ``d`` (``shape`` forces a launch shape of the fused kernel)."""
     from keypoints2body_amd import native
     cfg = native.default_fit_config()
+    cfg.debug_launch_shape = LAUNCH_SHAPES[shape]
     cfg.num_iters = int(d["num_iters"]) if num_iters is None else int(num_iters)
     cfg.pose_preserve_weight = 5.0 if int(d["seq_ind"]) > 0 else 0.0
     cfg.freeze_betas = int(d["freeze_betas"])

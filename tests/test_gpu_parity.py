@@ -146,20 +146,19 @@ def test_fit_matches_reference_golden(case):
 
 
 @pytest.mark.parametrize("shape", ["split", "split_paired", "paired"])
-def test_every_launch_shape_matches_reference_golden(shape, monkeypatch):
+def test_every_launch_shape_matches_reference_golden(shape):
     """The fit kernel has three launch shapes chosen by frames per CU (row + tree wave per frame, row + tree
-    wave per two frames, one wave for two frames).  K2B_FIT_MODE forces a shape so that each one is pinned to the reference
+    wave per two frames, one wave for two frames).  `k2b_fit_config.debug_launch_shape` forces a shape so that each one is pinned to the reference
     goldens, including a ragged batch that leaves half a paired wave and several MFMA columns empty."""
-    monkeypatch.setenv("K2B_FIT_MODE", shape)
     for case in ("amass_batched", "amass_followup", "smpl24_zero_init"):
         d = H.load_case(case)
-        out = H.native_fit(d)
+        out = H.native_fit(d, shape=shape)
         for key in ("global_orient", "body_pose", "betas", "transl"):
             err = np.abs(out[key].cpu().numpy() - d["out_" + key]).max()
             assert err < PARAM_TOL, f"{shape}/{case}: {key} differs by {err}"
 
 
-def test_launch_shapes_agree_bitwise_on_a_ragged_batch(monkeypatch):
+def test_launch_shapes_agree_bitwise_on_a_ragged_batch():
     """Same arithmetic in every shape: loss and gradient of 37 frames (up to 10 workgroups with ragged tails) are bit-identical across shapes."""
     from keypoints2body_amd import native, synthetic
     B = 37
@@ -171,7 +170,7 @@ def test_launch_shapes_agree_bitwise_on_a_ragged_batch(monkeypatch):
     cfg = native.default_fit_config(); cfg.num_iters = 3
     res = {}
     for shape in ("split", "split_paired", "paired"):
-        monkeypatch.setenv("K2B_FIT_MODE", shape)
+        cfg.debug_launch_shape = H.LAUNCH_SHAPES[shape]
         res[shape] = native.fit_world(m, pr, cfg, list(range(22)), j3d, None, go * 0.9, bp * 0.9, be * 0.5, tr, want_grad=True)
     for shape in ("split_paired", "paired"):
         for k in ("global_orient", "body_pose", "betas", "transl", "loss", "grad"):
@@ -179,7 +178,7 @@ def test_launch_shapes_agree_bitwise_on_a_ragged_batch(monkeypatch):
 
 
 @pytest.mark.parametrize("shape", ["split", "split_paired", "paired"])
-def test_sixteen_beta_model_matches_oracle(shape, monkeypatch):
+def test_sixteen_beta_model_matches_oracle(shape):
     """Models with more than 10 betas run the 16-beta instantiation of the fit kernel.  No reference golden
     exists for that size (the reference ships 10-beta SMPL); the oracle restatement - pinned to the reference
     on the 10-beta cases - is the checker here, on a 16-beta synthetic model with a small mesh."""
@@ -187,7 +186,6 @@ def test_sixteen_beta_model_matches_oracle(shape, monkeypatch):
     from keypoints2body_amd.native import NativeModel
     from oracle.fit_torch import fit_world_adam
     from oracle.smpl_torch import TorchSMPL
-    monkeypatch.setenv("K2B_FIT_MODE", shape)
     c = synthetic.make_body_model(seed=3, num_vertices=512, num_betas=16)
     model = NativeModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents, c.extra_vertex_ids)
     oracle = TorchSMPL(c)
@@ -201,6 +199,7 @@ def test_sixteen_beta_model_matches_oracle(shape, monkeypatch):
     tr0 = t(p.transl) + 0.02
     ref = fit_world_adam(oracle, H.oracle_prior(), go0, bp0, be0, tr0, j3d, num_iters=iters)
     cfg = native.default_fit_config(); cfg.num_iters = iters
+    cfg.debug_launch_shape = H.LAUNCH_SHAPES[shape]
     out = native.fit_world(model, H.native_prior(), cfg, list(range(22)), j3d.cuda().contiguous(), None,
                            go0.cuda(), bp0.cuda(), be0.cuda(), tr0.cuda())
     for key, want in (("global_orient", ref.global_orient), ("body_pose", ref.body_pose), ("betas", ref.betas), ("transl", ref.transl)):
@@ -354,13 +353,12 @@ def _random_configuration(seed):
 
 
 @pytest.mark.parametrize("seed", list(range(1, 13)))
-def test_random_configurations_match_oracle(seed, monkeypatch):
+def test_random_configurations_match_oracle(seed):
     """Seeded sweep over the configuration space against the oracle (itself pinned to the reference on the golden
     cases), each case in one of the three launch shapes: parameters within 1e-4, last-iteration loss within 2e-4
     relative."""
     from keypoints2body_amd import native
     shape = ("split", "split_paired", "paired")[(seed // 3) % 3]
-    monkeypatch.setenv("K2B_FIT_MODE", shape)
     from oracle.fit_torch import FitWeights, fit_world_adam, guess_init_transl
     c = _random_configuration(seed)
     oracle = H.oracle_model()
@@ -377,6 +375,7 @@ def test_random_configurations_match_oracle(seed, monkeypatch):
                          weights=FitWeights(**c["weights"]), freeze_betas=c["freeze_betas"])
     cfg = native.default_fit_config()
     cfg.num_iters = c["iters"]
+    cfg.debug_launch_shape = H.LAUNCH_SHAPES[shape]
     for k, v in c["weights"].items():
         setattr(cfg, k, v)
     if c["seq_ind"] == 0:

@@ -26,9 +26,45 @@ def test_mixture_buffers_match_reference_derivation():
         MixtureBuffers.from_mixture(g["means"], g["covars"][:, :5], g["weights"])
 
 
-def test_missing_prior_file_exits_like_reference():
-    with pytest.raises(SystemExit):          # reference core/prior.py:126-131 calls sys.exit(-1)
+def test_missing_prior_file_raises_instead_of_exiting():
+    # the reference prints and calls sys.exit(-1) (core/prior.py:126-131); a library raises instead
+    with pytest.raises(FileNotFoundError):
         MixtureBuffers.from_file("/nonexistent/gmm_08.pkl")
+
+
+def test_prior_pickle_loads_arrays_and_refuses_code(tmp_path):
+    """The reference's gmm_XX.pkl is a Python-2 pickle of a dict of numpy arrays (prior.py:133-139): it must load,
+    bit-identically to the .npz form, through an unpickler that resolves numpy array globals only; a pickle that
+    names any other global (an sklearn object, os.system, ...) must be refused without being executed."""
+    import pickle
+    g = H.gmm_fixture()
+    covars = g["covars"].astype(np.float64)
+    good = tmp_path / "gmm_08.pkl"
+    with open(good, "wb") as f:
+        pickle.dump({"means": g["means"], "covars": covars, "weights": g["weights"]}, f, protocol=2)
+    b = MixtureBuffers.from_file(str(good))
+    np.savez(tmp_path / "gmm.npz", means=g["means"], covars=covars, weights=g["weights"])
+    z = MixtureBuffers.from_file(str(tmp_path / "gmm.npz"))
+    assert np.array_equal(b.means, z.means) and np.array_equal(b.precisions, z.precisions)
+    assert np.array_equal(b.nll_weights, z.nll_weights) and np.isfinite(b.nll_weights).all()
+
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {marker}",))
+
+    bad = tmp_path / "evil.pkl"
+    with open(bad, "wb") as f:
+        pickle.dump({"means": Evil()}, f, protocol=2)
+    with pytest.raises(ValueError, match="only plain dicts of numpy arrays"):
+        MixtureBuffers.from_file(str(bad))
+    assert not marker.exists()
+    with open(bad, "wb") as f:
+        pickle.dump([1, 2, 3], f, protocol=2)
+    with pytest.raises(ValueError, match="Unknown content"):
+        MixtureBuffers.from_file(str(bad))
 
 
 def test_c_abi_exports_every_declared_symbol():

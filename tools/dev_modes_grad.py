@@ -13,7 +13,7 @@ for B in (1, 2, 3, 5, 17, 40):
     cfg = native.default_fit_config(); cfg.num_iters = 1; cfg.step_size = 0.0
     res = {}
     for mode in ('split', 'split_paired', 'paired'):
-        os.environ['K2B_FIT_MODE'] = mode
+        cfg.debug_launch_shape = H.LAUNCH_SHAPES[mode]
         o = native.fit_world(m, pr, cfg, list(range(22)), j3d, None, go * 0.9, bp * 0.9, be * 0.5, tr, want_grad=True)
         res[mode] = (o['loss'].cpu().numpy(), o['grad'].cpu().numpy())
     l0, g0 = res['split']
