@@ -74,6 +74,27 @@ class CameraSpaceFitter:
             raise ValueError(f"expected a (B,{cols}) tensor, got {tuple(t.shape)}")
         return t.contiguous()
 
+    def stage_configs(self, seq_ind, joint_loss_weight=600.0, pose_preserve_weight=5.0, freeze_betas=True,
+                      depth_w=200.0):
+        """Kernel configurations of the two stages: ``(cfg1, cfg2, fit_betas)``.
+
+        Stage 1 (``camera_space.py:137-213``): ``[global_orient, camera_translation]`` (``optimize_mask = 9``),
+        plain squared error on the stage's joints (GMoF sigma -> inf, weight 1), depth prior ``depth_w^2 |t - t0|^2``
+        (200 = the reference's 100 broadcast over the four torso joints, ``losses.py:91-93``), every other prior off.
+        Stage 2 (``:215-298``): ``body_fitting_loss_3d``; betas optimised iff ``seq_ind == 0 or not freeze_betas``."""
+        cfg1 = native.default_fit_config()
+        cfg1.num_iters, cfg1.step_size = int(self.num_iters), float(self.step_size)
+        cfg1.sigma, cfg1.joint_loss_weight = _SQUARED_ERROR_SIGMA, 1.0
+        cfg1.pose_prior_weight = cfg1.angle_prior_weight = cfg1.shape_prior_weight = cfg1.pose_preserve_weight = 0.0
+        cfg1.optimize_mask, cfg1.transl_prior_weight = 9, float(depth_w)
+        cfg2 = native.default_fit_config()
+        cfg2.num_iters, cfg2.step_size = int(self.num_iters), float(self.step_size)
+        cfg2.joint_loss_weight = float(joint_loss_weight)
+        cfg2.pose_preserve_weight = float(pose_preserve_weight) if seq_ind > 0 else 0.0
+        fit_betas = seq_ind == 0 or not freeze_betas
+        cfg2.optimize_mask = 15 if fit_betas else 11
+        return cfg1, cfg2, fit_betas
+
     def fit_frame(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
                   seq_ind: int = 0, target_model_indices: Optional[torch.Tensor] = None,
                   joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = True,
@@ -121,19 +142,7 @@ class CameraSpaceFitter:
                 return dict(p, loss=r["loss"])
             return adam_with_vertex_joints(self.smpl, self.pose_prior, cfg, idx, tgt, cf, *cur, transl_prior_target=cam_t0)
 
-        # stage 1: [global_orient, camera_translation] on the torso joints
-        cfg1 = native.default_fit_config()
-        cfg1.num_iters, cfg1.step_size = int(self.num_iters), float(self.step_size)
-        cfg1.sigma, cfg1.joint_loss_weight = _SQUARED_ERROR_SIGMA, 1.0
-        cfg1.pose_prior_weight = cfg1.angle_prior_weight = cfg1.shape_prior_weight = cfg1.pose_preserve_weight = 0.0
-        cfg1.optimize_mask, cfg1.transl_prior_weight = 9, depth_w
-        # stage 2: body fit with a fresh optimiser state
-        cfg2 = native.default_fit_config()
-        cfg2.num_iters, cfg2.step_size = int(self.num_iters), float(self.step_size)
-        cfg2.joint_loss_weight = float(joint_loss_weight)
-        cfg2.pose_preserve_weight = float(pose_preserve_weight) if seq_ind > 0 else 0.0
-        fit_betas = seq_ind == 0 or not freeze_betas
-        cfg2.optimize_mask = 15 if fit_betas else 11
+        cfg1, cfg2, fit_betas = self.stage_configs(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas, depth_w)
         start = dict(global_orient=go, body_pose=bp, betas=be, transl=cam_t0)
         if self.use_lbfgs:
             s2 = self._two_stages_lbfgs(cfg1, cfg2, fit_betas, stage1_idx, stage1_tgt, model_idx, targets, conf, start, cam_t0)
