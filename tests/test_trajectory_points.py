@@ -10,10 +10,10 @@ gradient it obtained.  Here every such point is evaluated again:
 * GPU (``-m gpu``): by an evaluate-only launch of the fused HIP kernel through the C ABI (``num_iters = 1``,
   ``step_size = 0``, ``grad_out``) - exactly what the engine contributes to those modes.
 
-Tolerances.  CPU: the oracle, evaluated one call at a time like the reference (B = 1), reproduces the recorded loss
-and gradient to the last bit on the build machine; gated at 2e-6 to allow for another CPU's BLAS dispatch.  GPU: loss
-1e-5 relative; gradient 2e-5 of the call's scale, where scale = max(largest entry of that call's gradient, 2 % of the
-largest entry over the fit's whole trajectory).  The floor is the reference's OWN summation noise: late in a fit the
+Tolerances (both legs): loss 1e-5 relative; gradient 2e-5 of the call's scale, where scale = max(largest entry of that
+call's gradient, 2 % of the largest entry over the fit's whole trajectory).  (The oracle, evaluated one call at a time
+with the generator's thread count, reproduces the records to the last bit; with another thread count or batched it does
+not, which is what sets the bar.)  The floor is the reference's OWN summation noise: late in a fit the
 gradient is a small difference of large terms (entries ~1e4 left of ~1e6 partial sums), and merely evaluating the same
 torch code batched instead of call by call moves such an entry by 2.6e-5 of the call's largest entry (measured:
 ``traj_camera_adam_default_start`` stage 2, call 34, d/d transl) - any other fp32 summation order differs at that level.
@@ -94,7 +94,7 @@ def test_oracle_matches_reference_along_world_lbfgs_trajectory(name):
     d, foc = load(f"lbfgs_world_{name}")
     rows = np.arange(len(d["loss"]))
     loss, grad = oracle_eval(d, rows, foc, 0, int(d["seq_ind"]))
-    check(d, rows, loss, grad, f"oracle/world lbfgs {name}", foc, loss_rtol=2e-6, grad_rtol=2e-6, floor=0.0)
+    check(d, rows, loss, grad, f"oracle/world lbfgs {name}", foc)
 
 
 @pytest.mark.parametrize("name", CAMERA)
@@ -103,7 +103,7 @@ def test_oracle_matches_reference_along_camera_trajectory(name):
     for stage in (1, 2):
         rows = np.nonzero(d["stage"] == stage)[0]
         loss, grad = oracle_eval(d, rows, foc, stage, int(d["seq_ind"]), cam_t0=d["cam_t0"])
-        check(d, rows, loss, grad, f"oracle/{name} stage {stage}", foc, loss_rtol=2e-6, grad_rtol=2e-6, floor=0.0)
+        check(d, rows, loss, grad, f"oracle/{name} stage {stage}", foc)
 
 
 # ---------------------------------------------------------------------------------------------------
