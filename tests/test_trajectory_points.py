@@ -10,10 +10,11 @@ gradient it obtained.  Here every such point is evaluated again:
 * GPU (``-m gpu``): by an evaluate-only launch of the fused HIP kernel through the C ABI (``num_iters = 1``,
   ``step_size = 0``, ``grad_out``) - exactly what the engine contributes to those modes.
 
-Tolerances (both legs): loss 1e-5 relative; gradient 2e-5 of the call's scale, where scale = max(largest entry of that
-call's gradient, 2 % of the largest entry over the fit's whole trajectory).  (The oracle, evaluated one call at a time
-with the generator's thread count, reproduces the records to the last bit; with another thread count or batched it does
-not, which is what sets the bar.)  The floor is the reference's OWN summation noise: late in a fit the
+Tolerances (both legs): loss 1e-5 relative; gradient 5e-5 of the call's scale, where scale = max(largest entry of that
+call's gradient, 2 % of the largest entry over the fit's whole trajectory).  The bar is set by torch's own noise: the
+oracle (the same torch ops as the reference), evaluated one call at a time with the generator's 8 threads, reproduces the
+records to the last bit; with 2 threads it deviates by 2.4e-5 of that scale (``lbfgs_world_first`` call 32), batched by
+2.6e-5 - so 2e-5 is below what the reference's code does to itself on another thread count.  The floor is the reference's OWN summation noise: late in a fit the
 gradient is a small difference of large terms (entries ~1e4 left of ~1e6 partial sums), and merely evaluating the same
 torch code batched instead of call by call moves such an entry by 2.6e-5 of the call's largest entry (measured:
 ``traj_camera_adam_default_start`` stage 2, call 34, d/d transl) - any other fp32 summation order differs at that level.
@@ -29,7 +30,7 @@ GROUPS = ("global_orient", "body_pose", "betas", "transl")
 WORLD = ("first", "followup", "frozen")
 CAMERA = ("camera_adam_default_start", "lbfgs_camera_first", "lbfgs_camera_followup_frozen")
 TORSO = [2, 1, 17, 16]          # RHip, LHip, RShoulder, LShoulder (reference core/constants.py, camera_space.py:16-41)
-LOSS_RTOL, GRAD_RTOL, FLOOR = 1e-5, 2e-5, 0.02
+LOSS_RTOL, GRAD_RTOL, FLOOR = 1e-5, 5e-5, 0.02
 
 
 def load(name):
