@@ -170,6 +170,10 @@ int k2b_lbs(const k2b_model *model, int32_t num_frames, const float *global_orie
             const float *body_pose, const float *betas, const float *transl,
             float *joints_out, float *vertices_out, void *stream);
 
+/* Development knob (A/B timing only, not part of the product interface): 0 = the tile kernel (default),
+ * 1 = the 128 x 64 kernel of round 1.  Process-wide. */
+void k2b_debug_lbs_kernel(int32_t which);
+
 /* ---------------------------------------------------------------------------------
  * Vertex-selected joints in the loss (slow path).  `target_model_indices` of the reference
  * (world_space.py:198-201) may name smplx's "extra" joints, which are single mesh vertices

@@ -18,6 +18,7 @@
 namespace {
 
 thread_local std::string g_err;
+int g_lbs_kernel = 0;     // development knob (k2b_debug_lbs_kernel): 0 = tile kernel, 1 = the 128 x 64 kernel of round 1
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -75,8 +76,12 @@ struct k2b_model {
     // LBS B operands (f16 hi/lo, MFMA fragment order) for the whole mesh and for the E extra-joint vertices
     struct VertexSet {
         k2b::k2b_half *pdh = nullptr, *pdl = nullptr, *wth = nullptr, *wtl = nullptr;
+        k2b::k2b_half* w2 = nullptr;                         // W in the tile kernel's group layout (k2b_internal.h, TileArgs)
         int v_tiles = 0, num = 0;
     } mesh, extra;
+    int groups_a = 0;                                        // GA = ceil(J / 8)
+    k2b::k2b_half* wsA2 = nullptr;                           // per-frame A operand of the tile kernel
+    float* dump = nullptr;                                   // 64 x 3 floats: store target of lanes outside the batch
     int k_steps_x = 0, k_steps_a = 0;
     // LBS per-frame operand workspace (grow-only)
     k2b::k2b_half *wsXh = nullptr, *wsXl = nullptr, *wsAh = nullptr, *wsAl = nullptr;
@@ -166,6 +171,8 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         const int KX = ((P + NB + 2 + 31) / 32) * 2, KA = (J + 15) / 16;   // even: the kernel stages 32-deep slices
         m->k_steps_x = KX;
         m->k_steps_a = KA;
+        m->groups_a = k2b::tile_groups_a(J);
+        HIP_TRY(hipMalloc((void**)&m->dump, 64 * 3 * sizeof(float)));
         auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids) -> int {
             const int n = (int)ids.size();
             vs.num = n;
@@ -203,7 +210,24 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                     wtl[o] = (k2b::k2b_half)(w - (float)hi);
                 }
             }
+            // tile-kernel layout of W: [16-vertex tile][hi groups | lo groups | ONES | ZERO][16 rows][8 joints]
+            const int GA = k2b::tile_groups_a(J), NGP = k2b::tile_ngp(GA), v16 = vs.v_tiles * 2;
+            std::vector<k2b::k2b_half> w2((size_t)v16 * NGP * 128, (k2b::k2b_half)0.f);
+            for (int t = 0; t < v16; ++t)
+                for (int r = 0; r < 16; ++r) {
+                    const int i = t * 16 + r;
+                    k2b::k2b_half* rowp = w2.data() + ((size_t)t * NGP * 16 + r) * 8;
+                    if (i < n)
+                        for (int j = 0; j < J; ++j) {
+                            const float w = lbs_weights[(size_t)ids[i] * J + j];
+                            const k2b::k2b_half hi = (k2b::k2b_half)w;
+                            rowp[(size_t)(j >> 3) * 128 + (j & 7)] = hi;
+                            rowp[(size_t)(GA + (j >> 3)) * 128 + (j & 7)] = (k2b::k2b_half)(w - (float)hi);
+                        }
+                    for (int k = 0; k < 3; ++k) rowp[(size_t)(2 * GA) * 128 + k] = (k2b::k2b_half)1.f;   // ONES: picks up the PAD terms
+                }
             hipError_t e;
+            if ((e = upload(&vs.w2, w2.data(), w2.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdh, pdh.data(), pdh.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdl, pdl.data(), pdl.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.wth, wth.data(), wth.size())) != hipSuccess) return (int)e;
@@ -305,7 +329,8 @@ void k2b_model_destroy(k2b_model* m) {
                    m->j_dirs, m->dt, m->dd};
     for (float* p : fl) if (p) (void)hipFree(p);
     k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->mesh.wth, m->mesh.wtl, m->extra.pdh, m->extra.pdl,
-                           m->extra.wth, m->extra.wtl, m->wsXh, m->wsXl, m->wsAh, m->wsAl};
+                           m->extra.wth, m->extra.wtl, m->wsXh, m->wsXl, m->wsAh, m->wsAl, m->mesh.w2, m->extra.w2, m->wsA2};
+    if (m->dump) (void)hipFree(m->dump);
     for (k2b::k2b_half* p : hl) if (p) (void)hipFree(p);
     if (m->parents) (void)hipFree(m->parents);
     if (m->extra_ids) (void)hipFree(m->extra_ids);
@@ -314,6 +339,8 @@ void k2b_model_destroy(k2b_model* m) {
     for (auto& kv : m->adam_tables) (void)hipFree(kv.second.dev);
     delete m;
 }
+
+void k2b_debug_lbs_kernel(int32_t which) { g_lbs_kernel = which; }
 
 int k2b_model_dims(const k2b_model* m, int32_t* V, int32_t* J, int32_t* NB, int32_t* E) {
     if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_dims: model is NULL");
@@ -553,10 +580,13 @@ namespace {
 int reserve_lbs_workspace(k2b_model* m, int bpad) {
     if (bpad <= m->ws_bpad) return K2B_OK;
     HIP_TRY(hipDeviceSynchronize());
-    k2b::k2b_half** ws[] = {&m->wsXh, &m->wsXl, &m->wsAh, &m->wsAl};
+    k2b::k2b_half** ws[] = {&m->wsXh, &m->wsXl, &m->wsAh, &m->wsAl, &m->wsA2};
     for (auto w : ws) { if (*w) HIP_TRY(hipFree(*w)); *w = nullptr; }
     m->ws_bpad = 0;
     const size_t nx = (size_t)m->k_steps_x * bpad * 16, na = (size_t)12 * m->k_steps_a * bpad * 16;
+    const size_t na2 = (size_t)(bpad / 16) * 12 * k2b::tile_ngp(m->groups_a) * 128;
+    HIP_TRY(hipMalloc((void**)&m->wsA2, na2 * sizeof(k2b::k2b_half)));
+    HIP_TRY(hipMemset(m->wsA2, 0, na2 * sizeof(k2b::k2b_half)));    // PAD / ZERO groups and padding frames stay zero
     HIP_TRY(hipMalloc((void**)&m->wsXh, nx * sizeof(k2b::k2b_half)));
     HIP_TRY(hipMalloc((void**)&m->wsXl, nx * sizeof(k2b::k2b_half)));
     HIP_TRY(hipMalloc((void**)&m->wsAh, na * sizeof(k2b::k2b_half)));
@@ -597,9 +627,21 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     pa.num_joints = m->J; pa.num_betas = m->NB; pa.num_out_joints = m->J + m->E;
     pa.num_frames = B; pa.frames_padded = bpad; pa.k_steps_x = m->k_steps_x; pa.k_steps_a = m->k_steps_a;
     pa.go = go; pa.bp = bp; pa.be = be; pa.tr = tr;
-    pa.xh = m->wsXh; pa.xl = m->wsXl; pa.ah = m->wsAh; pa.al = m->wsAl; pa.joints_out = joints_out;
+    const bool tiles = (m->groups_a == 3 || m->groups_a == 7) && g_lbs_kernel != 1;   // 17-24 or 49-56 joints
+    if (!tiles && (m->k_steps_a != 2))
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_lbs: %d joints; the vertex kernels are built for 17-24 (SMPL) and 49-56 (SMPL-X) joints", m->J);
+    pa.xh = m->wsXh; pa.xl = m->wsXl; pa.joints_out = joints_out;
+    if (tiles) { pa.a2 = m->wsA2; } else { pa.ah = m->wsAh; pa.al = m->wsAl; }
     HIP_TRY(k2b::launch_pose_setup(pa, stream));
     auto skin = [&](const k2b_model::VertexSet& vs, float* out, int stride, int row0) -> hipError_t {
+        if (tiles) {
+            k2b::TileArgs ta{};
+            ta.xh = m->wsXh; ta.xl = m->wsXl; ta.a2 = m->wsA2; ta.pdh = vs.pdh; ta.pdl = vs.pdl; ta.w2 = vs.w2;
+            ta.groups_a = m->groups_a; ta.k_steps_x = m->k_steps_x; ta.f_tiles = bpad / 32; ta.v_tiles = vs.v_tiles;
+            ta.num_frames = B; ta.num_out = vs.num; ta.out = out; ta.out_stride = stride; ta.out_row0 = row0;
+            ta.dump = m->dump;
+            return k2b::launch_skin_tiles(ta, device_cus(), stream);
+        }
         k2b::SkinArgs sa{};
         sa.pdh = vs.pdh; sa.pdl = vs.pdl; sa.wth = vs.wth; sa.wtl = vs.wtl;
         sa.v_tiles = vs.v_tiles; sa.num_out = vs.num;

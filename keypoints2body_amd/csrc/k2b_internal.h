@@ -86,7 +86,8 @@ struct PoseArgs {
     int k_steps_x, k_steps_a;  // 16-deep k-steps of the vertex GEMM (features) and of the transform GEMM (joints)
     const float *go, *bp, *be, *tr;  // tr may be null
     k2b_half *xh, *xl;         // fragments [k_steps_x][frames_padded / 32]
-    k2b_half *ah, *al;         // fragments [12][k_steps_a][frames_padded / 32]
+    k2b_half *ah, *al;         // fragments [12][k_steps_a][frames_padded / 32]   (null: not written)
+    k2b_half* a2;              // group layout of the tile kernel (see TileArgs), or null
     float* joints_out;         // [B][num_out_joints][3] (first J rows written) or null
 };
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream);
@@ -105,6 +106,32 @@ struct SkinArgs {
     int out_stride, out_row0;
 };
 hipError_t launch_skin(const SkinArgs& a, hipStream_t stream);
+
+// ---- tile kernel (k2b_lbs_tile_kernel): 128 frames x 128 vertices per workgroup, persistent ------------------
+// Operands of the transform GEMM T = A . W^T in k-GROUPS of 8 joints over 16-row tiles (256 B = [16 rows][8 halfs]):
+//   A  [16-frame tile][entry 12][NGP][16][8]   groups: hi_0..hi_{GA-1}, lo_0..lo_{GA-1}, PAD (translation terms), ZERO
+//   W  [16-vertex tile][NGP][16][8]            groups: hi_0..hi_{GA-1}, lo_0..lo_{GA-1}, ONES ([1,1,1,0,...] per row), ZERO
+// GA = ceil(J / 8), NGP = 2 GA + 2 (a multiple of 4: whole 1 KiB pieces).  The three f16-split products (hi.hi + hi.lo +
+// lo.hi) are ONE contraction over the concatenated group sequences  A: hi | hi | lo | PAD,  W: hi | lo | hi | ONES
+// (3 GA + 1 groups, padded to a multiple of four with ZERO): ceil((3 GA + 1) / 4) MFMAs of depth 32 per output tile, no
+// padding of J to 16, and the PAD x ONES position adds the frame's translation (three f16 terms) to the entries 3, 7, 11
+// inside the GEMM.
+constexpr int tile_groups_a(int J) { return (J + 7) / 8; }
+constexpr int tile_ngp(int GA) { return 2 * GA + 2; }
+struct TileArgs {
+    const k2b_half *xh, *xl;     // X fragments [k_steps_x][f_tiles]          (pose set-up)
+    const k2b_half *a2;          // A groups    [2 f_tiles][12][NGP][16][8]   (pose set-up)
+    const k2b_half *pdh, *pdl;   // Pd fragments [k_steps_x][3][v_tiles]      (model)
+    const k2b_half *w2;          // W groups    [2 v_tiles][NGP][16][8]       (model)
+    int groups_a;                // GA
+    int k_steps_x, f_tiles, v_tiles;
+    int num_frames, num_out;
+    float* out;                  // [B][out_stride][3], rows out_row0 .. out_row0 + num_out - 1
+    int out_stride, out_row0;
+    float* dump;                 // >= 64 x 3 floats: where lanes without a valid (frame, vertex) put their store
+    int num_wgs;                 // grid size (a multiple of 8), set by the launcher
+};
+hipError_t launch_skin_tiles(const TileArgs& a, int num_cus, hipStream_t stream);
 hipError_t launch_gather_joints(const float* verts, const int* ids, float* joints, int num_frames, int V, int J, int E,
                                 hipStream_t stream);
 

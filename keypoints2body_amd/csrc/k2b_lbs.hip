@@ -48,7 +48,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // ---------------------------------------------------------------------------------------------
 // Pose set-up: one 64-lane workgroup per frame, lane j = joint j.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxXSteps = 24;       // 16-deep k-steps of the feature vector this kernel can stage (SMPL: 14 or 16)
+constexpr int kMaxXSteps = 32;       // 16-deep k-steps of the feature vector this kernel can stage (SMPL: 14, SMPL-X: 32)
 
 __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     __shared__ float sR[kMaxJoints][9];
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     // per X k-step and 8 per (entry, joint k-step) of A.  (Element-wise 2-byte stores - 1200 per frame - made
     // this kernel store-issue bound.)
     __shared__ __attribute__((aligned(16))) _Float16 sXh[kMaxXSteps * 16], sXl[kMaxXSteps * 16];
-    __shared__ __attribute__((aligned(16))) _Float16 sAh[12][32], sAl[12][32];
+    __shared__ __attribute__((aligned(16))) _Float16 sAh[12][kMaxJoints], sAl[12][kMaxJoints];
+    __shared__ __attribute__((aligned(16))) _Float16 sTp[3][8];      // translation as three f16 terms (PAD group of the tile kernel)
     auto put_x = [&](int k, float x) {
         _Float16 hi, lo;
         split_f16(x, hi, lo);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         }
     }
     // A_j = [Rg | pg - Rg J_j] (k = joint; zero rows for the padded joints J .. 16 k_steps_a - 1)
-    if (j < 32) {
+    {
         const Vec3 rj = mul(Rg, Jj);
         const float At[12] = {Rg.m[0], Rg.m[1], Rg.m[2], pg.x - rj.x, Rg.m[3], Rg.m[4], Rg.m[5], pg.y - rj.y,
                               Rg.m[6], Rg.m[7], Rg.m[8], pg.z - rj.z};
@@ -155,11 +156,38 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
             const uint4 v = *reinterpret_cast<const uint4*>((lo ? sXl : sXh) + ks * 16 + 8 * h);
             *reinterpret_cast<uint4*>((lo ? a.xl : a.xh) + frag_elem((size_t)ks * tiles + tile, 8 * h, f)) = v;
         }
-        const int na = 12 * a.k_steps_a * 2;               // chunks per A array
+        const int na = a.ah ? 12 * a.k_steps_a * 2 : 0;    // chunks per A array (fragment layout of the 128 x 64 kernel)
         for (int c = j; c < 2 * na; c += 64) {
             const int lo = c >= na, cc = lo ? c - na : c, e = cc / (a.k_steps_a * 2), r = cc % (a.k_steps_a * 2), ks = r >> 1, h = r & 1;
             const uint4 v = *reinterpret_cast<const uint4*>((lo ? &sAl[e][0] : &sAh[e][0]) + ks * 16 + 8 * h);
             *reinterpret_cast<uint4*>((lo ? a.al : a.ah) + frag_elem(a_frag(e, ks, a.k_steps_a, tiles, tile), 8 * h, f)) = v;
+        }
+    }
+    if (a.a2) {
+        // group layout of the tile kernel: [16-frame tile][entry][hi groups | lo groups | PAD | ZERO][row 16][8]; the PAD group of
+        // the entries 3, 7, 11 carries the translation as three f16 terms (hi + mid + lo: 33 bits), ZERO is never written
+        if (j < 3) {
+            const float t = a.tr ? a.tr[(size_t)f * 3 + j] : 0.f;
+            const _Float16 t0 = (_Float16)t, t1 = (_Float16)(t - (float)t0), t2 = (_Float16)(t - (float)t0 - (float)t1);
+            sTp[j][0] = t0; sTp[j][1] = t1; sTp[j][2] = t2;
+            for (int i = 3; i < 8; ++i) sTp[j][i] = (_Float16)0.f;
+        }
+        __syncthreads();
+        const int GA = (J + 7) >> 3, NGP = 2 * GA + 2, tile = f >> 4, row = f & 15;
+        k2b_half* base = a.a2 + ((size_t)tile * 12 * NGP * 16 + row) * 8;
+        for (int c = j; c < 12 * 2 * GA + 3; c += 64) {
+            uint4 v;
+            size_t grp;             // (entry, group) index
+            if (c < 12 * 2 * GA) {
+                const int e = c / (2 * GA), r = c % (2 * GA), lo = r >= GA, g = lo ? r - GA : r;
+                v = *reinterpret_cast<const uint4*>((lo ? &sAl[e][0] : &sAh[e][0]) + 8 * g);
+                grp = (size_t)e * NGP + r;
+            } else {
+                const int r3 = c - 12 * 2 * GA;
+                v = *reinterpret_cast<const uint4*>(&sTp[r3][0]);
+                grp = (size_t)(4 * r3 + 3) * NGP + 2 * GA;
+            }
+            *reinterpret_cast<uint4*>(base + grp * 16 * 8) = v;
         }
     }
     if (!act) return;
@@ -383,6 +411,270 @@ __global__ __launch_bounds__(512, 1) void k2b_lbs_mfma_kernel(const SkinArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile kernel: workgroup = 8 waves = 128 frames x 128 vertices, persistent; v_mfma_f32_16x16x32_f16 throughout.
+//
+//   wave w: vertices [32 (w & 3), +32) (two 16-vertex tiles), frames [64 (w >> 2), +64) (four 16-frame tiles):
+//   8 accumulator tiles of 16 x 16 per coordinate, 96 registers in the pose phase.
+//
+// Per tile the operands stream through a TWO-slot ring of 64 KiB (global_load_lds_dwordx4, lane-linear 1 KiB pieces) as a
+// sequence of slices, one workgroup barrier per slice of 72 MFMAs per wave; the fills of slice q + 1 are issued at the top
+// of slice q.  Workgroups are persistent: the slice sequence runs on across tile boundaries, so the next tile's first
+// slice arrives under the present tile's last one and its stores.
+//   pose slice = one 32-deep k-step:  X 4 x 32 frames x 2 k-halves x hi/lo (16 pieces) + Pd 4 x 32 vertices x 3 coords
+//                                     x 2 k-halves x hi/lo (48 pieces): 72 MFMAs per wave (8 tiles x 3 coords x 3 products)
+//   transform slice u (u-th 16-frame tile of every wave), EPS entries in d-major order (e = 4 r + d):
+//                                     EPS x 2 frame tiles x NGP groups; EPS x NKT x 2 MFMAs per wave
+//   out_r += T_e * v_posed_d  (d < 3)   |   out_r += T_e  (d = 3; the translation arrives through the PAD x ONES position)
+// The transform phase works on ONE 16-frame tile at a time: 24 accumulator registers of outputs + 8 of T beside the 96 of
+// v_posed (which die tile by tile), so the three coordinates of a (frame, vertex) pair meet in registers and leave as ONE
+// 12-byte store - no LDS parking, no spills.  Bytes into LDS per 32 x 32 sub-tile: 41 KiB (128 x 64 kernel: 60 KiB).
+// ---------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int kTileSlotBytes = 64 * 1024;
+
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// the tiles of one workgroup: XCD label x = block % 8 owns a contiguous range of (frame chunk, vertex group) items,
+// a chunk = 8 frame groups (1024 frames: their per-frame operands, 2.3 MB, stay in the XCD's L2 while the vertex
+// groups stream past); inside the range the frame group runs fastest, the XCD's workgroups take every nx-th tile.
+struct TileWalk {
+    int vgroups, fgroups, item_lo, item_hi, nx;
+    int t;                      // index into the XCD's tile sequence (item-major, 8 frame slots per item)
+    int fg, vg;
+    bool valid;
+    __device__ void init(const TileArgs& a, int block, int nblocks) {
+        vgroups = (a.v_tiles + 3) >> 2; fgroups = (a.f_tiles + 3) >> 2;
+        const int items = ((fgroups + 7) >> 3) * vgroups, x = block & 7;
+        item_lo = (int)((long long)items * x / 8); item_hi = (int)((long long)items * (x + 1) / 8);
+        nx = nblocks >> 3;
+        t = (block >> 3) - nx;
+        next();
+    }
+    __device__ void next() {
+        for (;;) {
+            t += nx;
+            const int item = item_lo + (t >> 3);
+            if (item >= item_hi) { valid = false; return; }
+            const int c = item / vgroups;
+            fg = c * 8 + (t & 7); vg = item - c * vgroups;
+            if (fg < fgroups) { valid = true; return; }
+        }
+    }
+};
+
+template <int GA, int EPS>
+__global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
+    constexpr int NGP = tile_ngp(GA);                 // 256-byte groups per (entry, 16-frame tile) and per 16-vertex tile of W
+    constexpr int LSEQ = 3 * GA + 1;                  // k-groups of the concatenated contraction
+    constexpr int NKT = (LSEQ + 3) / 4;               // MFMAs (32-deep k-steps) per entry and output tile
+    constexpr int NTS = 12 / EPS;                     // transform slices per 16-frame tile
+    constexpr int TP = EPS * 2 * (NGP / 4);           // pieces of a transform slice
+    constexpr int WP = 8 * (NGP / 4);                 // pieces of the resident W image (8 tiles of 16 vertices)
+    static_assert(12 % EPS == 0 && NGP % 4 == 0 && TP % 8 == 0 && WP % 8 == 0, "piece counts must divide over 8 waves");
+    static_assert(TP * 1024 <= kTileSlotBytes, "transform slice does not fit a ring slot");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 slots][64 KiB] | W image [8][NGP][256 B]
+    unsigned char* const wimg = lds + 2 * kTileSlotBytes;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int vt = wave & 3, fpair = wave >> 2;
+    const int g = lane >> 4, row = lane & 15;         // MFMA 16x16x32 operand lane: row of the tile, k-group of the step
+    const int ftiles = a.f_tiles, vtiles = a.v_tiles, KX = a.k_steps_x >> 1;   // 32-deep k-steps (k_steps_x is even)
+    const int f16tiles = ftiles * 2;
+
+    // lane offsets inside a pose slot: piece (k-half, ...) = two 512-byte groups over 32 rows ([group][row32][8])
+    const int lx = (g >> 1) * (8 * 1024) + (g & 1) * 512 + row * 16;     // X pieces:  [k-half][frame tile 4][hi/lo]
+    const int lp = (g >> 1) * (24 * 1024) + (g & 1) * 512 + row * 16;    // Pd pieces: 16 KiB + [k-half][vertex tile 4][coord 3][hi/lo]
+    // group offsets (inside an entry / a vertex tile) of this lane for the k-steps of the transform GEMM
+    int offA[NKT], offW[NKT];
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+        auto seqA = [](int p) { return p < GA ? p : p < 2 * GA ? p - GA : p < 3 * GA ? p - GA : p == 3 * GA ? 2 * GA : 2 * GA + 1; };
+        auto seqW = [](int p) { return p < GA ? p : p < 2 * GA ? p : p < 3 * GA ? p - 2 * GA : p == 3 * GA ? 2 * GA : 2 * GA + 1; };
+        const int pa = g == 0 ? seqA(4 * i) : g == 1 ? seqA(4 * i + 1) : g == 2 ? seqA(4 * i + 2) : seqA(4 * i + 3);
+        const int pw = g == 0 ? seqW(4 * i) : g == 1 ? seqW(4 * i + 1) : g == 2 ? seqW(4 * i + 2) : seqW(4 * i + 3);
+        offA[i] = pa * 256 + row * 16;
+        offW[i] = pw * 256 + row * 16;
+    }
+
+    auto ftile_c = [&](int fgx, int t) { const int x = fgx * 4 + t; return x < ftiles ? x : ftiles - 1; };
+    auto vtile_c = [&](int vgx, int t) { const int x = vgx * 4 + t; return x < vtiles ? x : vtiles - 1; };
+    const int lane8 = lane * 8;                       // halfs: this lane's 16 bytes of a 1 KiB piece
+
+    // ---- loader: a cursor one slice ahead of the consumer (all quantities wave-uniform) ------------------------------
+    TileWalk lw;
+    lw.init(a, blockIdx.x, a.num_wgs);
+    int ls = 0;                   // slice of the loader's tile to issue next
+    int lq = 0;                   // global slice counter of the loader (slot = lq & 1)
+    const int spt = KX + 4 * NTS; // slices per tile
+    auto issue = [&]() {
+        if (!lw.valid) return;
+        unsigned char* slot = lds + (lq & 1) * kTileSlotBytes;
+        if (ls < KX) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = wave + 8 * i;                              // compile-time kind: i < 2 -> X, else Pd
+                const k2b_half* src;
+                if (i < 2) {                                             // X: [k-half][frame tile][hi/lo]
+                    const int kh = p >> 3, ft = (p >> 1) & 3;
+                    src = ((p & 1) ? a.xl : a.xh) + ((size_t)(2 * ls + kh) * ftiles + ftile_c(lw.fg, ft)) * kFragHalfs;
+                } else {                                                 // Pd: [k-half][vertex tile][coord][hi/lo]
+                    const int i2 = p - 16, kh = i2 / 24, r24 = i2 - kh * 24, v4 = r24 / 6, c = (r24 - v4 * 6) >> 1;
+                    src = ((i2 & 1) ? a.pdl : a.pdh) + (((size_t)(2 * ls + kh) * 3 + c) * vtiles + vtile_c(lw.vg, v4)) * kFragHalfs;
+                }
+                __builtin_amdgcn_global_load_lds(src + lane8, slot + p * 1024, 16, 0, 0);
+            }
+        } else {
+            const int tsl = ls - KX, u = tsl / NTS, ts = tsl - u * NTS;
+#pragma unroll
+            for (int i = 0; i < TP / 8; ++i) {
+                const int p = wave + 8 * i;                              // piece: [entry in slice][frame tile of the slice][4 groups]
+                const int ei = p / (2 * (NGP / 4)), rem = p - ei * (2 * (NGP / 4)), fsel = rem / (NGP / 4), pc = rem - fsel * (NGP / 4);
+                const int nseq = ts * EPS + ei, d = nseq / 3, r = nseq - 3 * d, e = 4 * r + d;
+                int f16 = (lw.fg * 4 + 2 * fsel) * 2 + u;                // u-th 16-frame tile of wave pair fsel
+                f16 = f16 < f16tiles ? f16 : f16tiles - 1;
+                const k2b_half* src = a.a2 + (((size_t)f16 * 12 + e) * NGP + 4 * pc) * 128;
+                __builtin_amdgcn_global_load_lds(src + lane8, slot + p * 1024, 16, 0, 0);
+            }
+        }
+        ++lq;
+        if (++ls == spt) { ls = 0; lw.next(); }
+    };
+
+    // ---- consumer ------------------------------------------------------------------------------------------------
+    TileWalk cw;
+    cw.init(a, blockIdx.x, a.num_wgs);
+    if (!cw.valid) return;        // whole workgroup: no tile
+    int q = 0;                    // global slice counter of the consumer
+    issue();
+    wait_vmcnt<0>();
+    wg_barrier();
+
+    auto rd = [&](const unsigned char* base, int off) -> half8 { return *reinterpret_cast<const half8*>(base + off); };
+    const float inv_scale = 1.0f / kPdScale;
+
+    while (cw.valid) {
+        floatx4 vp[4][2][3];      // [16-frame tile][16-vertex tile][coordinate]
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vp[f][v][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- pose phase: v_posed * kPdScale = X . Pd ---------------------------------------------------------
+        for (int ks = 0; ks < KX; ++ks) {
+            issue();
+            if (ks == 0) {        // resident W image of this tile's vertex group (single buffer: every read of the previous
+                                  // tile's image lies before the barrier that ended its last slice)
+#pragma unroll
+                for (int i = 0; i < WP / 8; ++i) {
+                    const int p = wave + 8 * i, v16 = p / (NGP / 4), pc = p - v16 * (NGP / 4);
+                    int vt16 = cw.vg * 8 + v16;
+                    vt16 = vt16 < 2 * vtiles ? vt16 : 2 * vtiles - 1;
+                    const k2b_half* src = a.w2 + ((size_t)vt16 * NGP + 4 * pc) * 128;
+                    __builtin_amdgcn_global_load_lds(src + lane8, wimg + p * 1024, 16, 0, 0);
+                }
+            }
+            const unsigned char* slot = lds + (q & 1) * kTileSlotBytes;
+            const unsigned char* xb = slot + lx, *pb = slot + 16 * 1024 + lp;
+            half8 xf[4][2];       // [16-frame tile][hi/lo]
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    xf[f][hl] = rd(xb, ((2 * fpair + (f >> 1)) * 2 + hl) * 1024 + (f & 1) * 256);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                half8 pf[2][2];   // [16-vertex tile][hi/lo]
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) pf[v][hl] = rd(pb, (vt * 6 + c * 2 + hl) * 1024 + v * 256);
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        vp[f][v][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[f][0], pf[v][0], vp[f][v][c], 0, 0, 0);
+                        vp[f][v][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[f][0], pf[v][1], vp[f][v][c], 0, 0, 0);
+                        vp[f][v][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[f][1], pf[v][0], vp[f][v][c], 0, 0, 0);
+                    }
+            }
+            wait_vmcnt<0>();      // the next slice (and, in the first slice, the W image) has landed
+            wg_barrier();
+            ++q;
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vp[f][v][c] *= inv_scale;
+
+        // ---- transform phase: one 16-frame tile (u) at a time --------------------------------------------------------
+        const unsigned char* wb = wimg + (2 * vt) * NGP * 256;
+        const int v0 = (cw.vg * 4 + vt) * 32 + row;      // this lane's vertex in 16-vertex tile 0 (tile 1: + 16)
+        float* const orow = a.out + ((size_t)a.out_row0 + v0) * 3;
+        float* const dump = a.dump + lane * 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            floatx4 out[2][3];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) out[v][r] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ts = 0; ts < NTS; ++ts) {
+                issue();
+                const unsigned char* slot = lds + (q & 1) * kTileSlotBytes;
+#pragma unroll
+                for (int ei = 0; ei < EPS; ++ei) {
+                    const int nseq = ts * EPS + ei, d = nseq / 3, r = nseq % 3;
+                    const unsigned char* ab = slot + (ei * 2 + fpair) * NGP * 256;
+                    floatx4 t[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int k = 0; k < NKT; ++k) {
+                        const half8 af = rd(ab, offA[k]);
+#pragma unroll
+                        for (int v = 0; v < 2; ++v)
+                            t[v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, rd(wb, v * NGP * 256 + offW[k]), t[v], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        if (d < 3) out[v][r] += t[v] * vp[u][v][d];
+                        else out[v][r] += t[v];
+                    }
+                }
+                if (ts == NTS - 1) {
+                    // one 12-byte store per (frame, vertex); lanes without a valid pair store to the dump row, so that every
+                    // wave issues the same number of vector-memory operations (the counted wait below relies on it)
+                    const int fbase = (cw.fg * 4 + 2 * fpair) * 32 + u * 16 + 4 * g;     // frame of accumulator register 0
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int f = fbase + i;
+                            float3v o;
+                            o.x = out[v][0][i]; o.y = out[v][1][i]; o.z = out[v][2][i];
+                            const bool ok = f < a.num_frames && v0 + 16 * v < a.num_out;
+                            float* dst = ok ? orow + ((size_t)f * a.out_stride + 16 * v) * 3 : dump;
+                            *reinterpret_cast<float3v*>(dst) = o;
+                        }
+                    wait_vmcnt<8>();      // all but the eight stores: the next slice has landed
+                } else {
+                    wait_vmcnt<0>();
+                }
+                wg_barrier();
+                ++q;
+            }
+        }
+        cw.next();
+    }
+    wait_vmcnt<0>();
+}
+
 // joints J..J+E-1 := vertices[extra ids] (when the full mesh has just been produced)
 __global__ void k2b_gather_joints_kernel(const float* __restrict__ verts, const int* __restrict__ ids, float* joints,
                                          int num_frames, int V, int J, int E) {
@@ -398,7 +690,8 @@ int lbs_frames_padded(int num_frames) { return (num_frames + 31) / 32 * 32; }
 
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
-    if (a.k_steps_x > kMaxXSteps || a.k_steps_a * 16 > 32 || a.num_joints > 32) return hipErrorInvalidValue;
+    if (a.k_steps_x > kMaxXSteps || a.num_joints > kMaxJoints || (a.ah && (a.k_steps_a * 16 > 32 || a.num_joints > 32)))
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL(k2b_pose_setup_kernel, dim3(a.num_frames), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
@@ -409,6 +702,35 @@ hipError_t launch_skin(const SkinArgs& a, hipStream_t stream) {
     const int vgroups = (a.v_tiles + 1) / 2, fgroups = (a.f_tiles + 3) / 4;
     const int vl = (vgroups + 7) / 8, chunks = (fgroups + kChunkGroups - 1) / kChunkGroups;
     hipLaunchKernelGGL(k2b_lbs_mfma_kernel, dim3(8 * vl * kChunkGroups * chunks), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_skin_tiles(const TileArgs& a_in, int num_cus, hipStream_t stream) {
+    if (a_in.num_frames <= 0 || a_in.num_out <= 0) return hipSuccess;
+    TileArgs a = a_in;
+    const int vgroups = (a.v_tiles + 3) / 4, fgroups = (a.f_tiles + 3) / 4;
+    const long long tiles = (long long)vgroups * fgroups;
+    int wgs = num_cus < 8 ? 8 : num_cus / 8 * 8;           // one persistent workgroup per CU, a multiple of the 8 XCD labels
+    if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
+    a.num_wgs = wgs;
+    const int GA = a.groups_a;
+    const size_t lds = (size_t)2 * kTileSlotBytes + (size_t)8 * tile_ngp(GA) * 256;
+    if (a.k_steps_x & 1) return hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+#define K2B_TILE(GA_, EPS_)                                                                                          \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            e = hipFuncSetAttribute((const void*)k2b_lbs_tile_kernel<GA_, EPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                           \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k2b_lbs_tile_kernel<GA_, EPS_>), dim3(wgs), dim3(512), lds, stream, a);                  \
+    } while (0)
+    if (GA == 3) K2B_TILE(3, 12);
+    else if (GA == 7) K2B_TILE(7, 6);
+    else return hipErrorInvalidValue;                      // 17..24 joints (SMPL) or 49..56 (SMPL-X)
+#undef K2B_TILE
     return hipGetLastError();
 }
 
