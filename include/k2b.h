@@ -173,6 +173,9 @@ int k2b_lbs(const k2b_model *model, int32_t num_frames, const float *global_orie
 /* Development knob (A/B timing only, not part of the product interface): 0 = the tile kernel (default),
  * 1 = the 128 x 64 kernel of round 1.  Process-wide. */
 void k2b_debug_lbs_kernel(int32_t which);
+/* Development: copies the first nbytes (<= 64 KiB) of the model's scratch row (where diagnostic builds leave their
+ * in-kernel time stamps) to HOST memory; synchronises the device. */
+int k2b_debug_read_dump(const k2b_model *model, void *host, int64_t nbytes);
 
 /* ---------------------------------------------------------------------------------
  * Vertex-selected joints in the loss (slow path).  `target_model_indices` of the reference

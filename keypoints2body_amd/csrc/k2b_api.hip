@@ -172,7 +172,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         m->k_steps_x = KX;
         m->k_steps_a = KA;
         m->groups_a = k2b::tile_groups_a(J);
-        HIP_TRY(hipMalloc((void**)&m->dump, 64 * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&m->dump, 64 * 1024));     // 64 x 3 floats used; the rest is room for diagnostic builds
         auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids) -> int {
             const int n = (int)ids.size();
             vs.num = n;
@@ -341,6 +341,12 @@ void k2b_model_destroy(k2b_model* m) {
 }
 
 void k2b_debug_lbs_kernel(int32_t which) { g_lbs_kernel = which; }
+int k2b_debug_read_dump(const k2b_model* m, void* host, int64_t nbytes) {
+    if (!m || !host || nbytes < 0 || nbytes > 64 * 1024) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_debug_read_dump: bad arguments");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, m->dump, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return K2B_OK;
+}
 
 int k2b_model_dims(const k2b_model* m, int32_t* V, int32_t* J, int32_t* NB, int32_t* E) {
     if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_dims: model is NULL");

@@ -432,6 +432,17 @@ __global__ __launch_bounds__(512, 1) void k2b_lbs_mfma_kernel(const SkinArgs a) 
 // ---------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int kTileSlotBytes = 64 * 1024;
+// Timing-only diagnostic builds (tools/build_lbs_variants.sh; never the shipped library):
+//   K2B_TILE_DIAG 1: every store goes to the dump row     2: only the first slice is ever filled (stale LDS afterwards)
+//   3: no MFMAs (fills, LDS reads, barriers, stores only)  5: stores land in the rows of the first 32 frames only (an
+//   L2-resident footprint: no HBM write stream)            6: s_memtime stamps of every slice of one tile (tools/dev_lbs_stamps.py)
+//   K2B_TILE_CHUNK: frame groups per L2 chunk (default 8)
+#ifndef K2B_TILE_DIAG
+#define K2B_TILE_DIAG 0
+#endif
+#ifndef K2B_TILE_CHUNK
+#define K2B_TILE_CHUNK 8
+#endif
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -446,7 +457,7 @@ struct TileWalk {
     bool valid;
     __device__ void init(const TileArgs& a, int block, int nblocks) {
         vgroups = (a.v_tiles + 3) >> 2; fgroups = (a.f_tiles + 3) >> 2;
-        const int items = ((fgroups + 7) >> 3) * vgroups, x = block & 7;
+        const int items = ((fgroups + K2B_TILE_CHUNK - 1) / K2B_TILE_CHUNK) * vgroups, x = block & 7;
         item_lo = (int)((long long)items * x / 8); item_hi = (int)((long long)items * (x + 1) / 8);
         nx = nblocks >> 3;
         t = (block >> 3) - nx;
@@ -455,14 +466,23 @@ struct TileWalk {
     __device__ void next() {
         for (;;) {
             t += nx;
-            const int item = item_lo + (t >> 3);
+            const int item = item_lo + t / K2B_TILE_CHUNK;
             if (item >= item_hi) { valid = false; return; }
             const int c = item / vgroups;
-            fg = c * 8 + (t & 7); vg = item - c * vgroups;
+            fg = c * K2B_TILE_CHUNK + t % K2B_TILE_CHUNK; vg = item - c * vgroups;
             if (fg < fgroups) { valid = true; return; }
         }
     }
 };
+
+__device__ __forceinline__ floatx4 tile_mfma(half8 x, half8 y, floatx4 c) {
+#if K2B_TILE_DIAG == 3
+    asm volatile("" ::"v"(x), "v"(y));      // operands stay live (their LDS reads are kept), no matrix instruction
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0);
+#endif
+}
 
 template <int GA, int EPS>
 __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
@@ -472,7 +492,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     constexpr int NTS = 12 / EPS;                     // transform slices per 16-frame tile
     constexpr int TP = EPS * 2 * (NGP / 4);           // pieces of a transform slice
     constexpr int WP = 8 * (NGP / 4);                 // pieces of the resident W image (8 tiles of 16 vertices)
-    static_assert(12 % EPS == 0 && NGP % 4 == 0 && TP % 8 == 0 && WP % 8 == 0, "piece counts must divide over 8 waves");
+    static_assert(12 % EPS == 0 && NGP % 4 == 0 && TP % 4 == 0 && WP % 4 == 0, "piece counts must divide over 8 waves");
     static_assert(TP * 1024 <= kTileSlotBytes, "transform slice does not fit a ring slot");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 slots][64 KiB] | W image [8][NGP][256 B]
     unsigned char* const wimg = lds + 2 * kTileSlotBytes;
@@ -503,40 +523,73 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     auto vtile_c = [&](int vgx, int t) { const int x = vgx * 4 + t; return x < vtiles ? x : vtiles - 1; };
     const int lane8 = lane * 8;                       // halfs: this lane's 16 bytes of a 1 KiB piece
 
-    // ---- loader: a cursor one slice ahead of the consumer (all quantities wave-uniform) ------------------------------
+    // ---- roles -----------------------------------------------------------------------------------------------------
+    // Waves w and w + 4 share a SIMD.  Everything that occupies a wave's instruction stream without feeding the matrix
+    // pipe - issuing the LDS-DMA fills (~75 cycles each), issuing stores against a busy store path (hundreds of cycles
+    // each) - is placed so that the SIMD partner is in its MFMA stream meanwhile (first version: all eight waves did
+    // both at the same points of a slice, and the matrix pipe idled 40 % of every slice):
+    //   loader waves 0-3:  top of slice: the stores of the PREVIOUS slice's outputs (held in 24 registers across the
+    //                      barrier), then ALL fills of the next slice (16 / 12 pieces); MFMAs; counted wait; barrier
+    //   waves 4-7:         MFMAs first (they start at once after the barrier); their stores at the end of the slice, when
+    //                      the loaders are in their MFMAs; no fills, so they never wait on the vector-memory counter.
+    const bool loader = wave < 4;
+
+    // ---- loader: a cursor one slice ahead of the consumer (all quantities wave-uniform, i.e. scalar registers) --------
+    // The source of every piece is  base pointer + 32-bit element offset + lane x 16 B.  What depends on the wave only is
+    // worked out once, what depends on the tile once per tile; per slice a piece costs an add or two (the first version
+    // redid the whole index arithmetic, divisions included, per piece: 900 cycles of scalar work per slice and wave).
     TileWalk lw;
     lw.init(a, blockIdx.x, a.num_wgs);
     int ls = 0;                   // slice of the loader's tile to issue next
     int lq = 0;                   // global slice counter of the loader (slot = lq & 1)
     const int spt = KX + 4 * NTS; // slices per tile
+    const int lwv = wave & 3;     // loader wave index: piece p = lwv + 4 i
+    const k2b_half* const xbase = (lwv & 1) ? a.xl : a.xh;        // hi / lo is the parity of the piece number
+    const k2b_half* const pbase = (lwv & 1) ? a.pdl : a.pdh;
+    unsigned poff[16];            // element offsets of this wave's 16 pose pieces at the loader's k-step
+    const unsigned xstride = 2u * ftiles * kFragHalfs, pstride = 2u * 3u * vtiles * kFragHalfs;   // per 32-deep k-step
     auto issue = [&]() {
         if (!lw.valid) return;
+#if K2B_TILE_DIAG == 2
+        if (lq > 0) { ++lq; if (++ls == spt) { ls = 0; lw.next(); } return; }
+#endif
         unsigned char* slot = lds + (lq & 1) * kTileSlotBytes;
         if (ls < KX) {
+            if (ls == 0) {        // new tile: offsets of the pieces at k-step 0
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int p = wave + 8 * i;                              // compile-time kind: i < 2 -> X, else Pd
-                const k2b_half* src;
-                if (i < 2) {                                             // X: [k-half][frame tile][hi/lo]
-                    const int kh = p >> 3, ft = (p >> 1) & 3;
-                    src = ((p & 1) ? a.xl : a.xh) + ((size_t)(2 * ls + kh) * ftiles + ftile_c(lw.fg, ft)) * kFragHalfs;
-                } else {                                                 // Pd: [k-half][vertex tile][coord][hi/lo]
-                    const int i2 = p - 16, kh = i2 / 24, r24 = i2 - kh * 24, v4 = r24 / 6, c = (r24 - v4 * 6) >> 1;
-                    src = ((i2 & 1) ? a.pdl : a.pdh) + (((size_t)(2 * ls + kh) * 3 + c) * vtiles + vtile_c(lw.vg, v4)) * kFragHalfs;
+                for (int i = 0; i < 16; ++i) {
+                    const int p = lwv + 4 * i;
+                    if (i < 4) {  // X: [k-half][frame tile][hi/lo]
+                        const int kh = p >> 3, ft = (p >> 1) & 3;
+                        poff[i] = (unsigned)(kh * ftiles + ftile_c(lw.fg, ft)) * kFragHalfs;
+                    } else {      // Pd: [k-half][vertex tile][coord][hi/lo]
+                        const int i2 = p - 16, kh = i2 / 24, r24 = i2 - kh * 24, v4 = r24 / 6, c = (r24 - v4 * 6) >> 1;
+                        poff[i] = (unsigned)((kh * 3 + c) * vtiles + vtile_c(lw.vg, v4)) * kFragHalfs;
+                    }
                 }
-                __builtin_amdgcn_global_load_lds(src + lane8, slot + p * 1024, 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const k2b_half* src = (i < 4 ? xbase : pbase) + poff[i];
+                __builtin_amdgcn_global_load_lds(src + lane8, slot + (lwv + 4 * i) * 1024, 16, 0, 0);
+                poff[i] += i < 4 ? xstride : pstride;
             }
         } else {
             const int tsl = ls - KX, u = tsl / NTS, ts = tsl - u * NTS;
+            unsigned fo[2];       // the u-th 16-frame tile of either wave pair
 #pragma unroll
-            for (int i = 0; i < TP / 8; ++i) {
-                const int p = wave + 8 * i;                              // piece: [entry in slice][frame tile of the slice][4 groups]
+            for (int fsel = 0; fsel < 2; ++fsel) {
+                int f16 = (lw.fg * 4 + 2 * fsel) * 2 + u;
+                f16 = f16 < f16tiles ? f16 : f16tiles - 1;
+                fo[fsel] = (unsigned)f16 * (12u * NGP * 128u);
+            }
+#pragma unroll
+            for (int i = 0; i < TP / 4; ++i) {
+                const int p = lwv + 4 * i;                               // piece: [entry in slice][frame tile of the slice][NGP / 4 pieces]
                 const int ei = p / (2 * (NGP / 4)), rem = p - ei * (2 * (NGP / 4)), fsel = rem / (NGP / 4), pc = rem - fsel * (NGP / 4);
                 const int nseq = ts * EPS + ei, d = nseq / 3, r = nseq - 3 * d, e = 4 * r + d;
-                int f16 = (lw.fg * 4 + 2 * fsel) * 2 + u;                // u-th 16-frame tile of wave pair fsel
-                f16 = f16 < f16tiles ? f16 : f16tiles - 1;
-                const k2b_half* src = a.a2 + (((size_t)f16 * 12 + e) * NGP + 4 * pc) * 128;
-                __builtin_amdgcn_global_load_lds(src + lane8, slot + p * 1024, 16, 0, 0);
+                const unsigned o = (fsel ? fo[1] : fo[0]) + (unsigned)((e * NGP + 4 * pc) * 128);
+                __builtin_amdgcn_global_load_lds(a.a2 + o + lane8, slot + p * 1024, 16, 0, 0);
             }
         }
         ++lq;
@@ -548,12 +601,56 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     cw.init(a, blockIdx.x, a.num_wgs);
     if (!cw.valid) return;        // whole workgroup: no tile
     int q = 0;                    // global slice counter of the consumer
-    issue();
+    if (loader) issue();
     wait_vmcnt<0>();
     wg_barrier();
 
     auto rd = [&](const unsigned char* base, int off) -> half8 { return *reinterpret_cast<const half8*>(base + off); };
     const float inv_scale = 1.0f / kPdScale;
+    float* const dump = a.dump + lane * 3;
+#if K2B_TILE_DIAG == 6
+    // stamps of the workgroup's THIRD tile, all 8 waves, 8 per slice, kept in the unused 16 KiB of LDS (no vector-memory
+    // traffic, so the counted waits are undisturbed) and copied out at the end by the blocks 0 and 77
+    unsigned* const stamps = reinterpret_cast<unsigned*>(wimg + 8 * NGP * 256);
+    int tile_no = 0;
+    auto stamp = [&](int slice, int k) {
+        if (tile_no == 2 && lane == 0) stamps[(wave * 32 + slice) * 8 + k] = (unsigned)__builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&](int, int) {};
+#endif
+
+    // one 12-byte store per (frame, vertex) of a 16-frame unit: frame fbase0 + 4 g + i, 16-vertex tile v
+    auto emit_stores = [&](const floatx4 (&o)[2][3], int fbase0, int vg) {
+        const int v0 = (vg * 4 + vt) * 32 + row;         // this lane's vertex in 16-vertex tile 0 (tile 1: + 16)
+        float* const orow = a.out + ((size_t)a.out_row0 + v0) * 3;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#if K2B_TILE_DIAG == 5
+                const int f = (fbase0 + 4 * g + i) & 31;
+                const bool ok = true;
+#elif K2B_TILE_DIAG == 1
+                const int f = 0;
+                const bool ok = false;
+#else
+                const int f = fbase0 + 4 * g + i;
+                const bool ok = f < a.num_frames && v0 + 16 * v < a.num_out;
+#endif
+                float3v x;
+                x.x = o[v][0][i]; x.y = o[v][1][i]; x.z = o[v][2][i];
+                float* dst = ok ? orow + ((size_t)f * a.out_stride + 16 * v) * 3 : dump;
+                *reinterpret_cast<float3v*>(dst) = x;
+            }
+    };
+    floatx4 pend[2][3];           // loader waves: outputs of the previous slice, stored at the top of the next one
+    int pend_f = 0, pend_vg = 0;
+    bool pend_valid = false;
+    auto slice_top = [&]() {      // loader waves only
+        if (pend_valid) { emit_stores(pend, pend_f, pend_vg); pend_valid = false; }
+        issue();
+    };
 
     while (cw.valid) {
         floatx4 vp[4][2][3];      // [16-frame tile][16-vertex tile][coordinate]
@@ -566,18 +663,22 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
 
         // ---- pose phase: v_posed * kPdScale = X . Pd ---------------------------------------------------------
         for (int ks = 0; ks < KX; ++ks) {
-            issue();
-            if (ks == 0) {        // resident W image of this tile's vertex group (single buffer: every read of the previous
+            stamp(ks, 0);
+            if (loader) {
+                slice_top();
+                if (ks == 0) {    // resident W image of this tile's vertex group (single buffer: every read of the previous
                                   // tile's image lies before the barrier that ended its last slice)
 #pragma unroll
-                for (int i = 0; i < WP / 8; ++i) {
-                    const int p = wave + 8 * i, v16 = p / (NGP / 4), pc = p - v16 * (NGP / 4);
-                    int vt16 = cw.vg * 8 + v16;
-                    vt16 = vt16 < 2 * vtiles ? vt16 : 2 * vtiles - 1;
-                    const k2b_half* src = a.w2 + ((size_t)vt16 * NGP + 4 * pc) * 128;
-                    __builtin_amdgcn_global_load_lds(src + lane8, wimg + p * 1024, 16, 0, 0);
+                    for (int i = 0; i < WP / 4; ++i) {
+                        const int p = lwv + 4 * i, v16 = p / (NGP / 4), pc = p - v16 * (NGP / 4);
+                        int vt16 = cw.vg * 8 + v16;
+                        vt16 = vt16 < 2 * vtiles ? vt16 : 2 * vtiles - 1;
+                        const k2b_half* src = a.w2 + ((size_t)vt16 * NGP + 4 * pc) * 128;
+                        __builtin_amdgcn_global_load_lds(src + lane8, wimg + p * 1024, 16, 0, 0);
+                    }
                 }
             }
+            stamp(ks, 1);
             const unsigned char* slot = lds + (q & 1) * kTileSlotBytes;
             const unsigned char* xb = slot + lx, *pb = slot + 16 * 1024 + lp;
             half8 xf[4][2];       // [16-frame tile][hi/lo]
@@ -597,13 +698,16 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
-                        vp[f][v][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[f][0], pf[v][0], vp[f][v][c], 0, 0, 0);
-                        vp[f][v][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[f][0], pf[v][1], vp[f][v][c], 0, 0, 0);
-                        vp[f][v][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[f][1], pf[v][0], vp[f][v][c], 0, 0, 0);
+                        vp[f][v][c] = tile_mfma(xf[f][0], pf[v][0], vp[f][v][c]);
+                        vp[f][v][c] = tile_mfma(xf[f][0], pf[v][1], vp[f][v][c]);
+                        vp[f][v][c] = tile_mfma(xf[f][1], pf[v][0], vp[f][v][c]);
                     }
             }
-            wait_vmcnt<0>();      // the next slice (and, in the first slice, the W image) has landed
+            stamp(ks, 2);
+            if (loader) wait_vmcnt<0>();      // the next slice (and, in the first slice, the W image) has landed
+            stamp(ks, 4);
             wg_barrier();
+            stamp(ks, 5);
             ++q;
         }
 #pragma unroll
@@ -614,10 +718,14 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 for (int c = 0; c < 3; ++c) vp[f][v][c] *= inv_scale;
 
         // ---- transform phase: one 16-frame tile (u) at a time --------------------------------------------------------
+        // the W fragments of this wave's two 16-vertex tiles stay in registers for the whole phase: re-read per entry they
+        // made the transform slices LDS-bandwidth-bound (108 KiB per wave and slice; with them resident 36 KiB)
         const unsigned char* wb = wimg + (2 * vt) * NGP * 256;
-        const int v0 = (cw.vg * 4 + vt) * 32 + row;      // this lane's vertex in 16-vertex tile 0 (tile 1: + 16)
-        float* const orow = a.out + ((size_t)a.out_row0 + v0) * 3;
-        float* const dump = a.dump + lane * 3;
+        half8 wf[2][NKT];
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int k = 0; k < NKT; ++k) wf[v][k] = rd(wb, v * NGP * 256 + offW[k]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             floatx4 out[2][3];
@@ -627,7 +735,9 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 for (int r = 0; r < 3; ++r) out[v][r] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ts = 0; ts < NTS; ++ts) {
-                issue();
+                stamp(KX + u * NTS + ts, 0);
+                if (loader) slice_top();
+                stamp(KX + u * NTS + ts, 1);
                 const unsigned char* slot = lds + (q & 1) * kTileSlotBytes;
 #pragma unroll
                 for (int ei = 0; ei < EPS; ++ei) {
@@ -639,7 +749,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                         const half8 af = rd(ab, offA[k]);
 #pragma unroll
                         for (int v = 0; v < 2; ++v)
-                            t[v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, rd(wb, v * NGP * 256 + offW[k]), t[v], 0, 0, 0);
+                            t[v] = tile_mfma(af, wf[v][k], t[v]);
                     }
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
@@ -647,32 +757,41 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                         else out[v][r] += t[v];
                     }
                 }
+                stamp(KX + u * NTS + ts, 2);
                 if (ts == NTS - 1) {
-                    // one 12-byte store per (frame, vertex); lanes without a valid pair store to the dump row, so that every
-                    // wave issues the same number of vector-memory operations (the counted wait below relies on it)
-                    const int fbase = (cw.fg * 4 + 2 * fpair) * 32 + u * 16 + 4 * g;     // frame of accumulator register 0
+                    const int fbase0 = (cw.fg * 4 + 2 * fpair) * 32 + u * 16;
+                    if (loader) {
 #pragma unroll
-                    for (int v = 0; v < 2; ++v)
+                        for (int v = 0; v < 2; ++v)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int f = fbase + i;
-                            float3v o;
-                            o.x = out[v][0][i]; o.y = out[v][1][i]; o.z = out[v][2][i];
-                            const bool ok = f < a.num_frames && v0 + 16 * v < a.num_out;
-                            float* dst = ok ? orow + ((size_t)f * a.out_stride + 16 * v) * 3 : dump;
-                            *reinterpret_cast<float3v*>(dst) = o;
-                        }
-                    wait_vmcnt<8>();      // all but the eight stores: the next slice has landed
-                } else {
-                    wait_vmcnt<0>();
+                            for (int r = 0; r < 3; ++r) pend[v][r] = out[v][r];
+                        pend_f = fbase0; pend_vg = cw.vg; pend_valid = true;
+                    } else {
+                        emit_stores(out, fbase0, cw.vg);
+                    }
                 }
+                stamp(KX + u * NTS + ts, 3);
+                if (loader) wait_vmcnt<0>();
+                stamp(KX + u * NTS + ts, 4);
                 wg_barrier();
+                stamp(KX + u * NTS + ts, 5);
                 ++q;
             }
         }
         cw.next();
+#if K2B_TILE_DIAG == 6
+        ++tile_no;
+#endif
     }
+    if (loader && pend_valid) emit_stores(pend, pend_f, pend_vg);
     wait_vmcnt<0>();
+#if K2B_TILE_DIAG == 6
+    if (blockIdx.x == 0 || blockIdx.x == 77) {
+        wg_barrier();
+        unsigned* dst = reinterpret_cast<unsigned*>(a.dump) + 1024 + (blockIdx.x ? 2048 : 0);
+        for (int i = threadIdx.x; i < 8 * 32 * 8; i += 512) dst[i] = stamps[i];
+    }
+#endif
 }
 
 // joints J..J+E-1 := vertices[extra ids] (when the full mesh has just been produced)

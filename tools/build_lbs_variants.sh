@@ -1,0 +1,13 @@
+#!/bin/bash
+# Timing-only variants of the LBS tile kernel: tools/libk2b_<name>.so (git-ignored; they travel to the GPU box).
+# usage: tools/build_lbs_variants.sh name:"-DFLAGS" ...     e.g.  nostore:"-DK2B_TILE_DIAG=1" chunk4:"-DK2B_TILE_CHUNK=4"
+set -e
+cd "$(dirname "$0")/../keypoints2body_amd/csrc"
+make -s -j8
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast -fno-slp-vectorize"
+for spec in "$@"; do
+  name="${spec%%:*}"; defs="${spec#*:}"
+  /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_lbs.hip -o /tmp/k2b_lbs_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libk2b_$name.so k2b_api.o k2b_fit.o /tmp/k2b_lbs_$name.o k2b_precompute.o k2b_metrics.o k2b_vertex.o
+  echo "built tools/libk2b_$name.so ($defs)"
+done
