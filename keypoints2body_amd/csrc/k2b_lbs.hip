@@ -443,6 +443,9 @@ constexpr int kTileSlotBytes = 64 * 1024;
 #ifndef K2B_TILE_CHUNK
 #define K2B_TILE_CHUNK 8
 #endif
+#ifndef K2B_TILE_TOUCH
+#define K2B_TILE_TOUCH 0
+#endif
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -504,21 +507,9 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     const int ftiles = a.f_tiles, vtiles = a.v_tiles, KX = a.k_steps_x >> 1;   // 32-deep k-steps (k_steps_x is even)
     const int f16tiles = ftiles * 2;
 
-    // lane offsets inside a pose slot: piece (k-half, ...) = two 512-byte groups over 32 rows ([group][row32][8])
-    const int lx = (g >> 1) * (8 * 1024) + (g & 1) * 512 + row * 16;     // X pieces:  [k-half][frame tile 4][hi/lo]
-    const int lp = (g >> 1) * (24 * 1024) + (g & 1) * 512 + row * 16;    // Pd pieces: 16 KiB + [k-half][vertex tile 4][coord 3][hi/lo]
-    // group offsets (inside an entry / a vertex tile) of this lane for the k-steps of the transform GEMM
-    int offA[NKT], offW[NKT];
-#pragma unroll
-    for (int i = 0; i < NKT; ++i) {
-        auto seqA = [](int p) { return p < GA ? p : p < 2 * GA ? p - GA : p < 3 * GA ? p - GA : p == 3 * GA ? 2 * GA : 2 * GA + 1; };
-        auto seqW = [](int p) { return p < GA ? p : p < 2 * GA ? p : p < 3 * GA ? p - 2 * GA : p == 3 * GA ? 2 * GA : 2 * GA + 1; };
-        const int pa = g == 0 ? seqA(4 * i) : g == 1 ? seqA(4 * i + 1) : g == 2 ? seqA(4 * i + 2) : seqA(4 * i + 3);
-        const int pw = g == 0 ? seqW(4 * i) : g == 1 ? seqW(4 * i + 1) : g == 2 ? seqW(4 * i + 2) : seqW(4 * i + 3);
-        offA[i] = pa * 256 + row * 16;
-        offW[i] = pw * 256 + row * 16;
-    }
-
+    // The per-lane LDS offsets are re-derived from the lane id at the start of each phase (behind an opaque copy, so
+    // that they are not hoisted out of the tile loop): eight registers less alive across the other phase.
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     auto ftile_c = [&](int fgx, int t) { const int x = fgx * 4 + t; return x < ftiles ? x : ftiles - 1; };
     auto vtile_c = [&](int vgx, int t) { const int x = vgx * 4 + t; return x < vtiles ? x : vtiles - 1; };
     const int lane8 = lane * 8;                       // halfs: this lane's 16 bytes of a 1 KiB piece
@@ -546,34 +537,55 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     const int lwv = wave & 3;     // loader wave index: piece p = lwv + 4 i
     const k2b_half* const xbase = (lwv & 1) ? a.xl : a.xh;        // hi / lo is the parity of the piece number
     const k2b_half* const pbase = (lwv & 1) ? a.pdl : a.pdh;
-    unsigned poff[16];            // element offsets of this wave's 16 pose pieces at the loader's k-step
-    const unsigned xstride = 2u * ftiles * kFragHalfs, pstride = 2u * 3u * vtiles * kFragHalfs;   // per 32-deep k-step
+    // element offsets of this wave's 16 pose pieces at the loader's k-step: lane i of ONE vector register holds piece i
+    // (read back with v_readlane; sixteen scalar registers instead pushed the kernel into scalar spills and s_load
+    // re-materialisation, whose lgkmcnt traffic forces full drains of the LDS reads)
+    unsigned vpoff = 0;
+    const unsigned vstride = lane < 4 ? 2u * ftiles * kFragHalfs : 2u * 3u * vtiles * kFragHalfs;   // per 32-deep k-step
+    int touched = 0;              // L2 touches issued behind the fills of the last slice (they may stay in flight)
+    int tsink = 0;                // their (never used) destination
     auto issue = [&]() {
+        touched = 0;
         if (!lw.valid) return;
 #if K2B_TILE_DIAG == 2
         if (lq > 0) { ++lq; if (++ls == spt) { ls = 0; lw.next(); } return; }
 #endif
         unsigned char* slot = lds + (lq & 1) * kTileSlotBytes;
         if (ls < KX) {
-            if (ls == 0) {        // new tile: offsets of the pieces at k-step 0
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int p = lwv + 4 * i;
-                    if (i < 4) {  // X: [k-half][frame tile][hi/lo]
-                        const int kh = p >> 3, ft = (p >> 1) & 3;
-                        poff[i] = (unsigned)(kh * ftiles + ftile_c(lw.fg, ft)) * kFragHalfs;
-                    } else {      // Pd: [k-half][vertex tile][coord][hi/lo]
-                        const int i2 = p - 16, kh = i2 / 24, r24 = i2 - kh * 24, v4 = r24 / 6, c = (r24 - v4 * 6) >> 1;
-                        poff[i] = (unsigned)((kh * 3 + c) * vtiles + vtile_c(lw.vg, v4)) * kFragHalfs;
-                    }
-                }
+            if (ls == 0) {        // new tile: offsets of the pieces at k-step 0 (lane i: piece p = lwv + 4 i)
+                const int p = lwv + 4 * (lane & 15);
+                const int kh = p >> 3, ft = (p >> 1) & 3;                                            // X: [k-half][frame tile][hi/lo]
+                const int i2 = p - 16, kh2 = i2 / 24, r24 = i2 - kh2 * 24, v4 = r24 / 6, c = (r24 - v4 * 6) >> 1;   // Pd: [k-half][vertex tile][coord][hi/lo]
+                const int ftc = lw.fg * 4 + ft < ftiles ? lw.fg * 4 + ft : ftiles - 1;
+                const int vtc = lw.vg * 4 + v4 < vtiles ? lw.vg * 4 + v4 : vtiles - 1;
+                vpoff = lane < 4 ? (unsigned)(kh * ftiles + ftc) * kFragHalfs : (unsigned)((kh2 * 3 + c) * vtiles + vtc) * kFragHalfs;
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const k2b_half* src = (i < 4 ? xbase : pbase) + poff[i];
+                const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)vpoff, i);
+                const k2b_half* src = (i < 4 ? xbase : pbase) + o;
                 __builtin_amdgcn_global_load_lds(src + lane8, slot + (lwv + 4 * i) * 1024, 16, 0, 0);
-                poff[i] += i < 4 ? xstride : pstride;
             }
+            vpoff += vstride;
+#if K2B_TILE_TOUCH
+            // L2 warm-up of the k-step AFTER the one just requested: one dword per 128-byte line of this wave's 16 pieces
+            // (128 lines), results never used.  LDS-DMA requests of a wave complete in order, so one L2 miss holds up every
+            // piece behind it: with ~20 % of the lines coming from beyond L2 the fill stream ran at the Infinity-Cache
+            // rate (27 GB/s per CU).  The touches fetch exactly those lines one slice earlier, at no LDS cost.
+            if (ls + 1 < KX) {
+                // scalar base + 32-bit lane offset: X pieces 0-3 (32 lines, both half-waves the same), Pd pieces 4-11, 12-15
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int pi = j == 0 ? ((lane >> 3) & 3) : j == 1 ? 4 + (lane >> 3) : 12 + ((lane >> 3) & 3);
+                    const unsigned o = ((unsigned)__shfl((int)vpoff, pi) + (lane & 7) * 64) * 2;     // bytes
+                    const k2b_half* sb = j == 0 ? xbase : pbase;
+                    // the destination stays reserved for the whole kernel ("+v" on a variable that lives across the tile
+                    // loop): the load returns long after the statement, into whatever the register would otherwise hold
+                    asm volatile("global_load_dword %0, %1, %2" : "+v"(tsink) : "v"(o), "s"(sb) : "memory");
+                }
+                touched = 3;
+            }
+#endif
         } else {
             const int tsl = ls - KX, u = tsl / NTS, ts = tsl - u * NTS;
             unsigned fo[2];       // the u-th 16-frame tile of either wave pair
@@ -647,9 +659,16 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     floatx4 pend[2][3];           // loader waves: outputs of the previous slice, stored at the top of the next one
     int pend_f = 0, pend_vg = 0;
     bool pend_valid = false;
-    auto slice_top = [&]() {      // loader waves only
-        if (pend_valid) { emit_stores(pend, pend_f, pend_vg); pend_valid = false; }
+    bool stored = false;
+    auto slice_top = [&]() {      // loader waves only: fills first (a wave's memory requests are taken in order, and the fills are
+                                  // what the next slice waits for), then the held outputs
         issue();
+        stored = pend_valid;
+        if (pend_valid) { emit_stores(pend, pend_f, pend_vg); pend_valid = false; }
+    };
+    auto loader_wait = [&]() {    // the fills have landed; the L2 touches and the eight stores behind them may fly on
+        if (stored) { if (touched) wait_vmcnt<11>(); else wait_vmcnt<8>(); }
+        else { if (touched) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
     };
 
     while (cw.valid) {
@@ -662,10 +681,13 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 for (int c = 0; c < 3; ++c) vp[f][v][c] = floatx4{0.f, 0.f, 0.f, 0.f};
 
         // ---- pose phase: v_posed * kPdScale = X . Pd ---------------------------------------------------------
+        // lane offsets inside a pose slot: piece (k-half, ...) = two 512-byte groups over 32 rows ([group][row32][8])
+        const int pl_ = opaque_lane(), pg_ = pl_ >> 4, pr_ = pl_ & 15;
+        const int lx = (pg_ >> 1) * (8 * 1024) + (pg_ & 1) * 512 + pr_ * 16;     // X pieces:  [k-half][frame tile 4][hi/lo]
+        const int lp = (pg_ >> 1) * (24 * 1024) + (pg_ & 1) * 512 + pr_ * 16;    // Pd pieces: 16 KiB + [k-half][vertex tile 4][coord 3][hi/lo]
         for (int ks = 0; ks < KX; ++ks) {
             stamp(ks, 0);
             if (loader) {
-                slice_top();
                 if (ks == 0) {    // resident W image of this tile's vertex group (single buffer: every read of the previous
                                   // tile's image lies before the barrier that ended its last slice)
 #pragma unroll
@@ -677,6 +699,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                         __builtin_amdgcn_global_load_lds(src + lane8, wimg + p * 1024, 16, 0, 0);
                     }
                 }
+                slice_top();
             }
             stamp(ks, 1);
             const unsigned char* slot = lds + (q & 1) * kTileSlotBytes;
@@ -704,7 +727,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                     }
             }
             stamp(ks, 2);
-            if (loader) wait_vmcnt<0>();      // the next slice (and, in the first slice, the W image) has landed
+            if (loader) loader_wait();        // the next slice (and, in the first slice, the W image) has landed
             stamp(ks, 4);
             wg_barrier();
             stamp(ks, 5);
@@ -720,6 +743,20 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
         // ---- transform phase: one 16-frame tile (u) at a time --------------------------------------------------------
         // the W fragments of this wave's two 16-vertex tiles stay in registers for the whole phase: re-read per entry they
         // made the transform slices LDS-bandwidth-bound (108 KiB per wave and slice; with them resident 36 KiB)
+        // group offsets (inside an entry / a vertex tile) of this lane for the k-steps of the transform GEMM
+        int offA[NKT], offW[NKT];
+        {
+            const int tl_ = opaque_lane(), tg_ = tl_ >> 4, tr_ = tl_ & 15;
+#pragma unroll
+            for (int i = 0; i < NKT; ++i) {
+                auto seqA = [](int p) { return p < GA ? p : p < 2 * GA ? p - GA : p < 3 * GA ? p - GA : p == 3 * GA ? 2 * GA : 2 * GA + 1; };
+                auto seqW = [](int p) { return p < GA ? p : p < 2 * GA ? p : p < 3 * GA ? p - 2 * GA : p == 3 * GA ? 2 * GA : 2 * GA + 1; };
+                const int pa = tg_ == 0 ? seqA(4 * i) : tg_ == 1 ? seqA(4 * i + 1) : tg_ == 2 ? seqA(4 * i + 2) : seqA(4 * i + 3);
+                const int pw = tg_ == 0 ? seqW(4 * i) : tg_ == 1 ? seqW(4 * i + 1) : tg_ == 2 ? seqW(4 * i + 2) : seqW(4 * i + 3);
+                offA[i] = pa * 256 + tr_ * 16;
+                offW[i] = pw * 256 + tr_ * 16;
+            }
+        }
         const unsigned char* wb = wimg + (2 * vt) * NGP * 256;
         half8 wf[2][NKT];
 #pragma unroll
@@ -739,23 +776,37 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 if (loader) slice_top();
                 stamp(KX + u * NTS + ts, 1);
                 const unsigned char* slot = lds + (q & 1) * kTileSlotBytes;
+                // software pipeline over the entries: the A fragments of entry n + 1 are requested before the MFMAs of
+                // entry n, and entry n - 1 is folded into the outputs while the matrix pipe works on entry n (left to the
+                // compiler, every entry paid an LDS round trip and an MFMA drain: 2.6-4.2 k cycles for 72 MFMAs)
+                half8 af[2][NKT];
+                floatx4 t[2][2];
 #pragma unroll
-                for (int ei = 0; ei < EPS; ++ei) {
-                    const int nseq = ts * EPS + ei, d = nseq / 3, r = nseq % 3;
-                    const unsigned char* ab = slot + (ei * 2 + fpair) * NGP * 256;
-                    floatx4 t[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+                for (int k = 0; k < NKT; ++k) af[0][k] = rd(slot + fpair * NGP * 256, offA[k]);
 #pragma unroll
-                    for (int k = 0; k < NKT; ++k) {
-                        const half8 af = rd(ab, offA[k]);
+                for (int ei = 0; ei <= EPS; ++ei) {
+                    if (ei + 1 < EPS) {
 #pragma unroll
-                        for (int v = 0; v < 2; ++v)
-                            t[v] = tile_mfma(af, wf[v][k], t[v]);
+                        for (int k = 0; k < NKT; ++k) af[(ei + 1) & 1][k] = rd(slot + ((ei + 1) * 2 + fpair) * NGP * 256, offA[k]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ei < EPS) {
 #pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        if (d < 3) out[v][r] += t[v] * vp[u][v][d];
-                        else out[v][r] += t[v];
+                        for (int v = 0; v < 2; ++v) t[ei & 1][v] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < NKT; ++k)
+#pragma unroll
+                            for (int v = 0; v < 2; ++v) t[ei & 1][v] = tile_mfma(af[ei & 1][k], wf[v][k], t[ei & 1][v]);
                     }
+                    if (ei > 0) {
+                        const int nseq = ts * EPS + ei - 1, d = nseq / 3, r = nseq % 3;
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            if (d < 3) out[v][r] += t[(ei - 1) & 1][v] * vp[u][v][d];
+                            else out[v][r] += t[(ei - 1) & 1][v];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 stamp(KX + u * NTS + ts, 2);
                 if (ts == NTS - 1) {
@@ -771,7 +822,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                     }
                 }
                 stamp(KX + u * NTS + ts, 3);
-                if (loader) wait_vmcnt<0>();
+                if (loader) loader_wait();
                 stamp(KX + u * NTS + ts, 4);
                 wg_barrier();
                 stamp(KX + u * NTS + ts, 5);
@@ -785,6 +836,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     }
     if (loader && pend_valid) emit_stores(pend, pend_f, pend_vg);
     wait_vmcnt<0>();
+    asm volatile("" ::"v"(tsink));
 #if K2B_TILE_DIAG == 6
     if (blockIdx.x == 0 || blockIdx.x == 77) {
         wg_barrier();

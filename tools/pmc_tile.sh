@@ -22,7 +22,7 @@ for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for f in glob.glob("$OUT/p*/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
-        if 'lbs_tile' in r['Kernel_Name'] and int(r['Grid_Size']) > 100000:
+        if 'lbs_tile' in r['Kernel_Name'] and int(r['Grid_Size_X']) > 100000:
             dur.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 print("frames $FR lib $LIB: tile kernel launches", len(dur), "avg", sum(dur) / max(1, len(dur)) / 1e3, "us")
 for k in sorted(acc): print(f"{k:32s} {sum(acc[k])/len(acc[k]):16.0f}  (n={len(acc[k])})")
