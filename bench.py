@@ -31,7 +31,9 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 # algorithmic work per unit (SURVEY.md §8d / DESIGN.md)
-FIT_FLOP_PER_FRAME_ITER = {"smpl": 0.11e6, "smplx": 0.13e6}   # analytic forward + backward + Adam, GMM prior dominates
+# analytic forward + backward + Adam per frame and iteration.  SMPL: mixture 8 x 69 x 69 x 2 = 76 k + chain / Rodrigues 12 k +
+# J(beta) 3 k + loss / Adam 2 k.  SMPL-X: mixture over 63 dimensions 64 k + 55-joint chain 27 k + J(shape) 13 k + loss / Adam 2 k.
+FIT_FLOP_PER_FRAME_ITER = {"smpl": 0.11e6, "smplx": 0.106e6}
 FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 HBM_PEAK_GBS = 8000.0
 ROUND = "r02"
@@ -76,9 +78,8 @@ def build_problem(total_frames, start, stop, seed, device, model_kind="smpl"):
     from keypoints2body_amd.models.smpl_data import SMPLData
     from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
 
-    if model_kind != "smpl":
-        from keypoints2body_amd import smplx_bench
-        return smplx_bench.build_problem(total_frames, start, stop, seed, device)
+    if model_kind == "smplx":
+        return build_problem_smplx(total_frames, start, stop, seed, device)
     model = BodyModel.synthetic(seed=0, device=device)
     gmm = synthetic.make_gmm(seed=0)
     prior = MaxMixturePrior(MixtureBuffers.from_mixture(gmm.means, gmm.covars, gmm.weights), device=device)
@@ -95,6 +96,32 @@ def build_problem(total_frames, start, stop, seed, device, model_kind="smpl"):
         j3d = gt.joints[:, :22].contiguous()
         transl0 = guess_init_transl_from_root(model, zeros(72), zeros(10), j3d, joints_category="AMASS")
     init = SMPLData(betas=zeros(10), global_orient=zeros(3), body_pose=zeros(69), transl=transl0.contiguous())
+    return model, prior, j3d, init
+
+
+def build_problem_smplx(total_frames, start, stop, seed, device):
+    """BASELINE config 4: SMPL-X-shaped model (55 joints, V = 10475, 10 betas + 10 expression coefficients), all 55 kinematic
+    joints observed (body, jaw, eyes, both hands), zero initialisation with a root-aligned translation."""
+    from keypoints2body_amd import synthetic
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.models.smpl_data import SMPLXData
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+
+    model = BodyModel.synthetic_x(seed=0, device=device)
+    gmm = synthetic.make_gmm(seed=0)
+    prior = MaxMixturePrior(MixtureBuffers.from_mixture(gmm.means, gmm.covars, gmm.weights), device=device)
+    poses = synthetic.make_poses_x(total_frames, seed=seed)
+    n = stop - start
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a[start:stop]), dtype=torch.float32, device=device).contiguous()
+    zeros = lambda c: torch.zeros((n, c), dtype=torch.float32, device=device)
+    fields = ("global_orient", "body_pose", "jaw_pose", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose", "betas",
+              "expression", "transl")
+    gt = model(**{k: dev(getattr(poses, k)) for k in fields}, return_verts=False)
+    j3d = gt.joints[:, :55].contiguous()
+    rest = model(global_orient=zeros(3), return_verts=False).joints
+    transl0 = (j3d[:, 0] - rest[:, 0]).contiguous()
+    init = SMPLXData(betas=zeros(10), global_orient=zeros(3), body_pose=zeros(63), transl=transl0, left_hand_pose=zeros(45),
+                     right_hand_pose=zeros(45), expression=zeros(10), jaw_pose=zeros(3), leye_pose=zeros(3), reye_pose=zeros(3))
     return model, prior, j3d, init
 
 
@@ -213,14 +240,19 @@ def main():
             per = (T + world - 1) // world
         model, prior, j3d, init = build_problem(T, start, stop, 1000, device, args.model)
         fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=args.iters, num_iters_followup=args.iters,
-                                  use_lbfgs=False, joints_category="AMASS", device=device, pose_prior=prior)
+                                  use_lbfgs=False, joints_category="AMASS" if args.model == "smpl" else "GENERIC",
+                                  device=device, pose_prior=prior)
         cfg = fitter._config(0, 600.0, 5.0, False, False)
+        K = j3d.shape[1]
+        if args.model == "smplx":
+            cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
+            init = fitter.packed_init(init)
         fit_ev, lbs_ev = [], []
 
         def step(record=False):
             e0, e1, e2 = ev(), ev(), ev()
             e0.record()
-            out = fitter.fit_params(cfg, j3d, init)
+            out = fitter.fit_params(cfg, j3d, init, list(range(K)))
             e1.record()
             # the parameter exchange is enqueued behind the fit and runs on RCCL's stream under the LBS launches
             gathered, work = gather_fit_outputs(out, dist, pad_to=per, async_op=True) if dist is not None else (None, None)
@@ -254,7 +286,7 @@ def main():
             "T": T, "frames_local": n_local, "elapsed": elapsed, "model": model,
             "fit_ms": float(np.mean([a.elapsed_time(b) for a, b in fit_ev])),      # HIP events on the launch stream
             "lbs_ms": float(np.mean([a.elapsed_time(b) for a, b in lbs_ev])),
-            "err_cm": float((joints[:, :22] - j3d).norm(dim=-1).mean().item() * 100) if n_local else 0.0,
+            "err_cm": float((joints[:, :K] - j3d).norm(dim=-1).mean().item() * 100) if n_local else 0.0,
             "loss": float(out["loss"].mean()) if n_local else 0.0,
         }
         return res
@@ -262,7 +294,7 @@ def main():
     weak = args.frames is not None
     main_res = measure(args.frames if weak else args.total_frames, weak, args.steps, args.warmup)
     weak_res = None
-    if not weak and not args.no_weak_line:
+    if not weak and not args.no_weak_line and args.model == "smpl":
         weak_res = measure(1024, True, args.steps, args.warmup)
 
     if rank == 0:
@@ -278,14 +310,16 @@ def main():
         n = model.native
         shape = (f"{'SMPL' if args.model == 'smpl' else 'SMPL-X'}-shaped model (V={n.num_vertices}, J={n.num_joints}, "
                  f"{n.num_betas} betas)")
+        targets = "22-joint AMASS" if args.model == "smpl" else "55-joint SMPL-X (body + jaw + eyes + hands)"
         if weak:
-            workload = (f"{args.frames} synthetic 22-joint AMASS frames per GPU, {shape}, {args.iters} Adam iters, "
+            workload = (f"{args.frames} synthetic {targets} frames per GPU, {shape}, {args.iters} Adam iters, "
                         "world mode, final joints+vertices produced")
         else:
-            workload = (f"{r['T']}-frame sequence of synthetic 22-joint AMASS frames sharded over {world} GPU(s) "
+            workload = (f"{r['T']}-frame sequence of synthetic {targets} frames sharded over {world} GPU(s) "
                         f"({F} frames on rank 0), {shape}, {args.iters} Adam iters, world mode, final joints+vertices produced")
         line = {
-            "metric": "SMPL frames fitted/sec (100 Adam iters, 22-joint AMASS)",
+            "metric": "SMPL frames fitted/sec (100 Adam iters, 22-joint AMASS)" if args.model == "smpl"
+                      else "SMPL-X frames fitted/sec (100 Adam iters, 55 kinematic joints)",
             "value": round(r["T"] * args.steps / r["elapsed"], 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -305,13 +339,13 @@ def main():
             # dominant kernel: the fused fit.  It never touches HBM inside its loop; its bound is fp32 vector-ALU issue
             # (DESIGN §4.1), so the peak is the fp32 VALU peak (= the fp32-input MFMA peak), not an f16 matrix peak.
             "roofline": {
-                "kernel": "k2b_fit_world_kernel", "bound": "valu", "achieved": round(fit_tflops, 3),
+                "kernel": "k2b_fit_world_kernel" if args.model == "smpl" else "k2b_fit_tree_kernel", "bound": "valu", "achieved": round(fit_tflops, 3),
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fit_tflops / FP32_PEAK_TFLOPS, 4),
                 "traffic": traffic, "avg_launch_ms": round(r["fit_ms"], 4),
-                "note": "algorithmic fp32 flops (0.11 MFLOP per frame-iteration) against the fp32 vector peak",
+                "note": f"algorithmic fp32 flops ({flop_iter / 1e6:.3f} MFLOP per frame-iteration) against the fp32 vector peak",
             },
             "roofline_lbs": {
-                "kernel": "k2b_pose_setup_kernel+k2b_lbs_mfma_kernel+k2b_gather_joints_kernel", "bound": "hbm",
+                "kernel": "k2b_pose_setup_kernel+k2b_lbs_tile_kernel+k2b_gather_joints_kernel", "bound": "hbm",
                 "achieved": round(lbs_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(lbs_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_lbs, "avg_launch_ms": round(r["lbs_ms"], 4),
                 "bytes_per_frame": lbs_bytes,
@@ -332,7 +366,7 @@ def main():
                                        / FP32_PEAK_TFLOPS, 4),
                 "lbs_frac_hbm": round(lbs_bytes * w["frames_local"] / (w["lbs_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "smpl":
             line["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_runs)
         print(json.dumps(line), flush=True)
     if dist is not None:

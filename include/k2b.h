@@ -61,7 +61,8 @@ const char *k2b_last_error(void);
  *   v_template  [V][3]        shapedirs [V][3][NB]      posedirs [9*(J-1)][3*V]
  *   j_regressor [J][V]        lbs_weights [V][J]        parents [J] (parents[0] = -1,
  *   extra_vertex_ids [E]      (output joints J..J+E-1 are these vertices)   parents[i] < i)
- * Limits: 2 <= J <= 64, 1 <= NB <= 16, E >= 0.
+ * Limits: 2 <= J <= 64, 1 <= NB <= 32, E >= 0.  (24 joints with NB <= 16 run the 24-lane fused fit kernel,
+ * everything else the tree kernel; the vertex kernels are built for 17-24 and 49-56 joints.)
  * ------------------------------------------------------------------------------- */
 int k2b_model_create(k2b_model **out, int32_t num_vertices, int32_t num_joints, int32_t num_betas,
                      int32_t num_extra_joints, const float *v_template, const float *shapedirs,
@@ -124,6 +125,13 @@ typedef struct k2b_fit_config {
      * 1, 2, 3 force the split / split-paired / paired shape of the fused kernel (and a single launch), so that
      * the parity tests can drive every shape with small cases.  Results do not depend on it. */
     int32_t debug_launch_shape;
+    /* Larger models (SMPL-H / SMPL-X): `body_pose` holds ALL non-root joints (SMPL-X: body 63 | jaw, eyes 9 | hands
+     * 90), `betas` all shape coefficients (betas | expression).  The mixture, the bending prior and the preserve term
+     * see the first prior_pose_dims values of body_pose (0 = all of them; SMPL-X: 63, the mixture's remaining
+     * dimensions fixed at 0); the shape prior and freeze_betas apply to the first num_betas_prior coefficients
+     * (0 = all; SMPL-X: 10, the expression stays free as in world_space.py:137-151,215-229). */
+    int32_t prior_pose_dims;
+    int32_t num_betas_prior;
 } k2b_fit_config;
 
 void k2b_fit_config_default(k2b_fit_config *cfg);

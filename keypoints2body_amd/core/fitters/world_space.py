@@ -19,8 +19,11 @@ the reference for B = 1 and deliberately differs (independent frames) for B > 1.
 
 Differences, all deliberate and documented in DESIGN.md:
 
-* hand / face parameters of ``SMPLHData`` / ``SMPLXData`` inputs are carried through
-  unchanged (the fused kernel fits the 24-joint SMPL tree);
+* SMPL-X (55-joint models, ``SMPLXData``): hands, jaw, eyes and expression join the optimiser exactly as in the
+  reference (``world_space.py:126-151,215-229``), fitted by the tree kernel (``csrc/k2b_fit_tree.hip``) over one packed
+  pose / shape vector.  The reference hands SMPL-X's 63-D body pose to its 69-D mixture, which raises (SURVEY.md N3);
+  here the mixture is evaluated at ``[body_pose | 0 x 6]``, and hands are full axis-angle poses (``use_pca=False``).
+  With a 24-joint model, hand / face fields of ``SMPLHData`` / ``SMPLXData`` inputs are carried through unchanged;
 * vertex-selected joints (model joint index >= 24: smplx's "extra" joints, single mesh vertices) take a slow
   path: the fused kernel fits kinematic joints only, so the Adam loop then runs on the host with three
   launches per iteration (``k2b_fit_world`` evaluate-only for the kinematic targets and the priors,
@@ -171,11 +174,19 @@ class WorldSpaceFitter:
         if j3d.dim() != 3 or j3d.shape[2] != 3:
             raise ValueError(f"j3d must be (B,K,3), got {tuple(j3d.shape)}")
         J = self.smpl.num_joints
-        go = self._dev(init_params.global_orient, 3)
-        bp = self._dev(init_params.body_pose, 3 * (J - 1))
-        be = self._dev(init_params.betas, self.smpl.num_betas)
-        tr = self._dev(init_params.transl, 3)
         B = j3d.shape[0]
+        smplx = self.smpl.model_type == "smplx"
+        go = self._dev(init_params.global_orient, 3)
+        if smplx:                                        # one pose vector of all non-root joints, one of all shape coefficients
+            get = lambda name: getattr(init_params, name, None)
+            bp = self.smpl.pack_pose(go.shape[0], body_pose=init_params.body_pose, jaw_pose=get("jaw_pose"),
+                                     leye_pose=get("leye_pose"), reye_pose=get("reye_pose"),
+                                     left_hand_pose=get("left_hand_pose"), right_hand_pose=get("right_hand_pose"))
+            be = self.smpl.pack_shape(go.shape[0], init_params.betas, get("expression"))
+        else:
+            bp = self._dev(init_params.body_pose, 3 * (J - 1))
+            be = self._dev(init_params.betas, self.smpl.num_betas)
+        tr = self._dev(init_params.transl, 3)
         if not (go.shape[0] == bp.shape[0] == be.shape[0] == tr.shape[0] == B):
             raise ValueError("init_params and j3d disagree on the number of frames")
 
@@ -205,6 +216,11 @@ class WorldSpaceFitter:
 
         cfg = self._config(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
                            per_frame_conf and conf is not None and conf.dim() == 2)
+        if smplx:
+            if self.use_lbfgs:
+                raise NotImplementedError("use_lbfgs=True with a 55-joint (SMPL-X) model: only the Adam branch is built for it")
+            cfg.prior_pose_dims = 3 * self.smpl.NUM_BODY_JOINTS       # 63: what the mixture, bending and preserve terms see
+            cfg.num_betas_prior = self.smpl.num_betas                 # 10: shape prior / freeze_betas leave the expression alone
         if any(i >= J for i in model_idx) and not self.use_lbfgs:
             out = self._fit_with_vertex_joints(cfg, model_idx, tgt, conf, go, bp, be, tr)
         elif self.use_lbfgs:
@@ -216,11 +232,23 @@ class WorldSpaceFitter:
         joints, verts = self.final_forward(out, want_vertices=want_vertices)
         return out, joints, verts, out["loss"]
 
-    def fit_params(self, cfg, targets, init):
+    def packed_init(self, init):
+        """Kernel layout of SMPL-X parameters: ``body_pose`` = all 162 non-root joint values, ``betas`` = betas | expression."""
+        B = init.global_orient.shape[0]
+        get = lambda name: getattr(init, name, None)
+        return SMPLData(global_orient=init.global_orient, transl=init.transl,
+                        body_pose=self.smpl.pack_pose(B, body_pose=init.body_pose, jaw_pose=get("jaw_pose"), leye_pose=get("leye_pose"),
+                                                      reye_pose=get("reye_pose"), left_hand_pose=get("left_hand_pose"),
+                                                      right_hand_pose=get("right_hand_pose")),
+                        betas=self.smpl.pack_shape(B, init.betas, get("expression")))
+
+    def fit_params(self, cfg, targets, init, model_idx=None):
         """The hot call alone: ONE fused-fit launch on device tensors that are already in kernel layout
-        (`targets` (B,K,3) in the order of this fitter's joint category, `init` on the device).  `bench.py` times
-        this + `final_forward`; `fit_batch` is the same two calls behind the reference's argument handling."""
-        return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, list(self.smpl_index), targets, None,
+        (`targets` (B,K,3) in the order of this fitter's joint category or of `model_idx`, `init` on the device, packed
+        for SMPL-X).  `bench.py` times this + `final_forward`; `fit_batch` is the same two calls behind the reference's
+        argument handling."""
+        idx = list(self.smpl_index) if model_idx is None else list(model_idx)
+        return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, targets, None,
                                 init.global_orient, init.body_pose, init.betas, init.transl)
 
     def final_forward(self, out, want_vertices=True):
@@ -302,6 +330,13 @@ class WorldSpaceFitter:
         out, joints, verts, loss = self.fit_batch(
             init_params, j3d, conf_3d, seq_ind, target_model_indices, joint_loss_weight, pose_preserve_weight,
             freeze_betas, per_frame_conf=False)
+        if self.smpl.model_type == "smplx":
+            u = self.smpl.unpack(out["body_pose"], out["betas"])
+            fitted = SMPLXData(betas=u["betas"], global_orient=out["global_orient"], body_pose=u["body_pose"],
+                               transl=out["transl"], left_hand_pose=u["left_hand_pose"], right_hand_pose=u["right_hand_pose"],
+                               expression=u["expression"], jaw_pose=u["jaw_pose"], leye_pose=u["leye_pose"],
+                               reye_pose=u["reye_pose"])
+            return BodyModelFitResult(params=fitted, vertices=verts, joints=joints, loss=loss.sum())
         fields = dict(betas=out["betas"], global_orient=out["global_orient"], body_pose=out["body_pose"],
                       transl=out["transl"])
         if isinstance(init_params, SMPLXData):

@@ -79,6 +79,10 @@ struct k2b_model {
         k2b::k2b_half* w2 = nullptr;                         // W in the tile kernel's group layout (k2b_internal.h, TileArgs)
         int v_tiles = 0, num = 0;
     } mesh, extra;
+    // tables of the tree fit kernel (any J <= 64), lane order = DFS pre-order
+    float *tt_dt = nullptr, *tt_dd = nullptr;
+    int* tt_tab = nullptr;
+    std::vector<int> tt_lane_of;                             // lane of every joint
     int groups_a = 0;                                        // GA = ceil(J / 8)
     k2b::k2b_half* wsA2 = nullptr;                           // per-frame A operand of the tile kernel
     float* dump = nullptr;                                   // 64 x 3 floats: store target of lanes outside the batch
@@ -98,6 +102,13 @@ struct k2b_prior {
     float *pa_image = nullptr, *row_const = nullptr, *nlw = nullptr;
     k2b::k2b_half* frag32 = nullptr;
     float inv_scale[k2b::kPriorMaxGauss] = {};
+    // host copies (symmetrised precisions in double, means, nll weights) and the mixture folded to its first Dv
+    // dimensions for the tree fit kernel, built on first use per Dv
+    std::vector<double> Ps, mu;
+    std::vector<float> nllw;
+    struct Folded { float *pA = nullptr, *ph = nullptr, *pb = nullptr, *pmu = nullptr, *pcl = nullptr; };
+    std::map<int, Folded> folded;
+    std::mutex mu_lock;
 };
 
 extern "C" {
@@ -128,6 +139,8 @@ void k2b_fit_config_default(k2b_fit_config* c) {
     c->optimize_mask = 15;
     c->transl_prior_weight = 0.0f;
     c->debug_launch_shape = 0;
+    c->prior_pose_dims = 0;
+    c->num_betas_prior = 0;
 }
 
 int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t E, const float* v_template,
@@ -135,8 +148,8 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                      const float* lbs_weights, const int32_t* parents, const int32_t* extra_vertex_ids) {
     if (!out) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: out is NULL");
     *out = nullptr;
-    if (V <= 0 || J < 2 || J > k2b::kMaxJoints || NB < 1 || NB > k2b::kMaxBetas || E < 0)
-        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: bad sizes V=%d J=%d NB=%d E=%d (need 2<=J<=64, 1<=NB<=16)", V, J, NB, E);
+    if (V <= 0 || J < 2 || J > k2b::kMaxJoints || NB < 1 || NB > k2b::kMaxShape || E < 0)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: bad sizes V=%d J=%d NB=%d E=%d (need 2<=J<=64, 1<=NB<=32)", V, J, NB, E);
     if (!v_template || !shapedirs || !posedirs || !j_regressor || !lbs_weights || !parents || (E > 0 && !extra_vertex_ids))
         return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: NULL constant array");
     if (parents[0] >= 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_model_create: parents[0] must be -1 (root)");
@@ -260,8 +273,8 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
 
     // tables of the fused fit kernel: lanes follow the DFS pre-order of the tree, so that every
     // subtree is a contiguous lane range
-    bool ok = (J == k2b::kFitJoints);
-    if (!ok) m->fit_why = "the fused fit kernel is built for the 24-joint SMPL tree";
+    bool ok = (J == k2b::kFitJoints) && NB <= k2b::kMaxBetas;
+    if (!ok) m->fit_why = "the 24-lane fused fit kernel is built for the 24-joint SMPL tree with <= 16 betas";
     std::vector<std::vector<int>> children(J);
     std::vector<int> depth(J, 0);
     int maxd = 0;
@@ -317,6 +330,25 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
     HIP_TRY(upload(&m->dd, dd.data(), dd.size()));
     HIP_TRY(upload(&m->tree, tab.data(), tab.size()));
     m->fit_ok = ok;
+    {   // tree fit kernel: [64][8] lane table (prior columns filled per call), rest offsets and their shape directions
+        std::vector<int> tt((size_t)64 * 8, -1);
+        std::vector<float> tdt((size_t)64 * 3, 0.f), tdd((size_t)64 * 3 * k2b::kMaxShape, 0.f);
+        for (int l = 0; l < 64; ++l) { tt[l * 8 + 1] = 0; tt[l * 8 + 2] = 1; tt[l * 8 + 3] = 1000; }
+        for (int l = 0; l < J; ++l) {
+            const int j = order[l], p = parents[j];
+            tt[l * 8 + 0] = j; tt[l * 8 + 1] = p >= 0 ? lane_of[p] : 0; tt[l * 8 + 2] = size[j]; tt[l * 8 + 3] = depth[j];
+            for (int c = 0; c < 3; ++c) {
+                tdt[l * 3 + c] = m->h_j_template[j * 3 + c] - (p >= 0 ? m->h_j_template[p * 3 + c] : 0.f);
+                for (int k = 0; k < NB; ++k)
+                    tdd[(l * 3 + c) * k2b::kMaxShape + k] =
+                        m->h_j_dirs[(j * 3 + c) * NB + k] - (p >= 0 ? m->h_j_dirs[(p * 3 + c) * NB + k] : 0.f);
+            }
+        }
+        m->tt_lane_of = lane_of;
+        HIP_TRY(upload(&m->tt_dt, tdt.data(), tdt.size()));
+        HIP_TRY(upload(&m->tt_dd, tdd.data(), tdd.size()));
+        HIP_TRY(upload(&m->tt_tab, tt.data(), tt.size()));
+    }
     guard.m = nullptr;
     *out = m;
     return K2B_OK;
@@ -331,6 +363,9 @@ void k2b_model_destroy(k2b_model* m) {
     k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->mesh.wth, m->mesh.wtl, m->extra.pdh, m->extra.pdl,
                            m->extra.wth, m->extra.wtl, m->wsXh, m->wsXl, m->wsAh, m->wsAl, m->mesh.w2, m->extra.w2, m->wsA2};
     if (m->dump) (void)hipFree(m->dump);
+    if (m->tt_dt) (void)hipFree(m->tt_dt);
+    if (m->tt_dd) (void)hipFree(m->tt_dd);
+    if (m->tt_tab) (void)hipFree(m->tt_tab);
     for (k2b::k2b_half* p : hl) if (p) (void)hipFree(p);
     if (m->parents) (void)hipFree(m->parents);
     if (m->extra_ids) (void)hipFree(m->extra_ids);
@@ -425,6 +460,9 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
     std::vector<k2b::k2b_half> f32((size_t)k2b::kPriorFrag32Halfs, (k2b::k2b_half)0.f);
     k2b_prior* p = new k2b_prior;
     p->M = M; p->D = D;
+    p->Ps = Ps;
+    p->mu.assign(means, means + (size_t)M * D);
+    p->nllw.assign(nll_weights, nll_weights + M);
     for (int m = 0; m < MG; ++m) p->inv_scale[m] = 1.0f;
     for (int m = 0; m < M; ++m) {
         double maxabs = 0.0;
@@ -470,8 +508,163 @@ void k2b_prior_destroy(k2b_prior* p) {
     float* fl[] = {p->pa_image, p->row_const, p->nlw};
     for (float* q : fl) if (q) (void)hipFree(q);
     if (p->frag32) (void)hipFree(p->frag32);
+    for (auto& kv : p->folded) {
+        float* fl2[] = {kv.second.pA, kv.second.ph, kv.second.pb, kv.second.pmu, kv.second.pcl};
+        for (float* q : fl2) if (q) (void)hipFree(q);
+    }
     delete p;
 }
+
+namespace {
+// Adam bias terms in double, exactly as torch/optim/adam.py computes them in Python floats; cached per model
+int adam_table(k2b_model* model, const k2b_fit_config* cfg, hipStream_t stream, float2** out) {
+    std::lock_guard<std::mutex> lk(model->mu);
+    const auto key = std::make_tuple((int)cfg->num_iters, cfg->step_size, cfg->adam_beta1, cfg->adam_beta2);
+    auto it = model->adam_tables.find(key);
+    if (it != model->adam_tables.end()) {
+        it->second.last_use = ++model->adam_clock;
+        *out = it->second.dev;
+        return K2B_OK;
+    }
+    std::vector<float2> h(cfg->num_iters);
+    const double lr = cfg->step_size, b1 = cfg->adam_beta1, b2 = cfg->adam_beta2;
+    for (int t = 1; t <= cfg->num_iters; ++t) {
+        const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
+        h[t - 1] = make_float2((float)(lr / bc1), (float)std::sqrt(bc2));
+    }
+    constexpr size_t kMaxAdamTables = 64;
+    if (model->adam_tables.size() >= kMaxAdamTables) {       // evict the least recently used table
+        auto victim = model->adam_tables.begin();
+        for (auto jt = model->adam_tables.begin(); jt != model->adam_tables.end(); ++jt)
+            if (jt->second.last_use < victim->second.last_use) victim = jt;
+        HIP_TRY(hipStreamSynchronize(stream));               // a launch in flight may still read it
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(victim->second.dev));
+        model->adam_tables.erase(victim);
+    }
+    float2* coef = nullptr;
+    HIP_TRY(upload(&coef, h.data(), h.size()));
+    model->adam_tables[key] = {coef, ++model->adam_clock};
+    *out = coef;
+    return K2B_OK;
+}
+
+// the mixture restricted to its first Dv dimensions, the others fixed at 0 (k2b_fit_tree.hip)
+int folded_prior(k2b_prior* p, int Dv, k2b_prior::Folded* out) {
+    std::lock_guard<std::mutex> lk(p->mu_lock);
+    auto it = p->folded.find(Dv);
+    if (it != p->folded.end()) { *out = it->second; return K2B_OK; }
+    const int M = p->M, D = p->D;
+    constexpr int MG = k2b::kPriorMaxGauss;
+    std::vector<float> A((size_t)MG * 16 * 64 * 4, 0.f), h((size_t)MG * 64, 0.f), b((size_t)MG * 64, 0.f), mu((size_t)MG * 64, 0.f), cl(MG, 0.f);
+    for (int m = 0; m < M; ++m) {
+        auto P = [&](int i, int j) { return p->Ps[((size_t)m * D + i) * D + j]; };
+        double c = 0.0;
+        for (int k = Dv; k < D; ++k)
+            for (int l = Dv; l < D; ++l) c += p->mu[(size_t)m * D + k] * P(k, l) * p->mu[(size_t)m * D + l];   // d_c = -mu_c
+        for (int i = 0; i < Dv; ++i) {
+            double bi = 0.0, Amu = 0.0;
+            for (int k = Dv; k < D; ++k) bi -= P(i, k) * p->mu[(size_t)m * D + k];
+            for (int j = 0; j < Dv; ++j) {
+                A[(((size_t)m * 16 + (j >> 2)) * 64 + i) * 4 + (j & 3)] = (float)P(i, j);
+                Amu += P(i, j) * p->mu[(size_t)m * D + j];
+            }
+            b[(size_t)m * 64 + i] = (float)bi;
+            h[(size_t)m * 64 + i] = (float)(bi - Amu);
+            mu[(size_t)m * 64 + i] = (float)p->mu[(size_t)m * D + i];
+        }
+        cl[m] = (float)(0.5 * c) - logf(p->nllw[m]);         // a weight that underflowed to 0 gives +inf: never the arg-min
+    }
+    k2b_prior::Folded f;
+    HIP_TRY(upload(&f.pA, A.data(), A.size()));
+    HIP_TRY(upload(&f.ph, h.data(), h.size()));
+    HIP_TRY(upload(&f.pb, b.data(), b.size()));
+    HIP_TRY(upload(&f.pmu, mu.data(), mu.size()));
+    HIP_TRY(upload(&f.pcl, cl.data(), cl.size()));
+    p->folded[Dv] = f;
+    *out = f;
+    return K2B_OK;
+}
+
+// large trees (SMPL-H / SMPL-X), or a prior over a prefix of the body pose: k2b_fit_tree.hip
+int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int prior_dims, int32_t B, int32_t K,
+             const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in, const float* bp_in,
+             const float* be_in, const float* tr_in, const float* preserve, const float* tr_prior, float* go_out, float* bp_out,
+             float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream) {
+    const int J = model->J, NB = model->NB;
+    if (prior_dims < 3 || prior_dims > 64 || prior_dims % 3 != 0 || prior_dims > prior->D || prior_dims > 3 * (J - 1))
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the tree kernel takes a prior over the first 3..63 body-pose dimensions "
+                    "(a multiple of 3, at most the mixture's %d), got %d", prior->D, prior_dims);
+    if (cfg->transl_prior_weight != 0.0f || tr_prior)
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the translation prior (camera-space fitter) is not built for %d-joint models", J);
+    if (B < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_frames=%d", B);
+    if (K < 1 || K > J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_targets=%d out of range", K);
+    if (!model_joint_index) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index is NULL");
+    if (cfg->num_iters < 1 || cfg->num_iters > (1 << 20)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_iters=%d", cfg->num_iters);
+    if (!(cfg->step_size >= 0.0) || !(cfg->adam_beta1 >= 0.0 && cfg->adam_beta1 < 1.0) || !(cfg->adam_beta2 >= 0.0 && cfg->adam_beta2 < 1.0))
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: bad Adam hyper-parameters");
+    if (B == 0) return K2B_OK;
+    if (!j3d || !go_in || !bp_in || !be_in || !tr_in || !go_out || !bp_out || !be_out || !tr_out)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: NULL parameter / target buffer (init transl is required, world_space.py:118-119)");
+    k2b::FitTreeArgs a{};
+    for (int l = 0; l < 64; ++l) a.lane_target[l] = -1;
+    int maxd = 0;
+    for (int k = 0; k < K; ++k) {
+        const int j = model_joint_index[k];
+        if (j < 0 || j >= J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index[%d]=%d out of range", k, j);
+        if (j >= J) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: model_joint_index[%d]=%d is a vertex-selected joint; the tree kernel fits kinematic joints only", k, j);
+        const int l = model->tt_lane_of[j];
+        if (a.lane_target[l] >= 0) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: joint %d is targeted twice", j);
+        a.lane_target[l] = k;
+        maxd = model->depth[j] > maxd ? model->depth[j] : maxd;
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int ai = cfg->angle_prior_index[i];
+        if (ai < 0 || ai >= prior_dims) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: angle_prior_index[%d]=%d must be in [0,%d)", i, ai, prior_dims);
+        a.angle_index[i] = ai;
+        a.angle_sign[i] = cfg->angle_prior_sign[i];
+    }
+    k2b_prior::Folded f;
+    if (const int rc = folded_prior(prior, prior_dims, &f); rc != K2B_OK) return rc;
+    float2* coef = nullptr;
+    if (const int rc = adam_table(model, cfg, (hipStream_t)stream, &coef); rc != K2B_OK) return rc;
+    {   // prior columns of the lane table (depend on prior_dims): uploaded once per model and value
+        static thread_local std::pair<const k2b_model*, int> last{nullptr, -1};
+        if (last.first != model || last.second != prior_dims) {
+            std::vector<int> cols((size_t)64 * 3, -1);
+            for (int i = 0; i < prior_dims; ++i) {               // prior dimension i = component i % 3 of joint 1 + i / 3
+                cols[i * 3 + 0] = model->tt_lane_of[1 + i / 3];
+                cols[i * 3 + 1] = i % 3;
+            }
+            for (int j = 1; j < J; ++j)
+                if (3 * (j - 1) + 2 < prior_dims) cols[model->tt_lane_of[j] * 3 + 2] = 3 * (j - 1);
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            for (int l = 0; l < 64; ++l)
+                HIP_TRY(hipMemcpy(model->tt_tab + l * 8 + 4, cols.data() + l * 3, 3 * sizeof(int), hipMemcpyHostToDevice));
+            last = {model, prior_dims};
+        }
+    }
+    a.dt = model->tt_dt; a.dd = model->tt_dd; a.tab = model->tt_tab;
+    a.num_joints = J; a.num_shape = NB; a.max_depth = maxd;
+    a.pA = f.pA; a.ph = f.ph; a.pb = f.pb; a.pmu = f.pmu; a.pcl = f.pcl;
+    a.num_gauss = prior->M; a.prior_dims = prior_dims;
+    a.num_frames = B; a.num_targets = K;
+    a.j3d = j3d; a.conf = conf; a.conf_per_frame = cfg->conf_per_frame ? 1 : 0;
+    a.go_in = go_in; a.bp_in = bp_in; a.be_in = be_in; a.tr_in = tr_in; a.preserve = preserve;
+    a.go_out = go_out; a.bp_out = bp_out; a.be_out = be_out; a.tr_out = tr_out; a.loss_out = loss_out; a.grad_out = grad_out;
+    a.adam_coef = coef; a.num_iters = cfg->num_iters;
+    a.one_minus_beta1 = (float)(1.0 - cfg->adam_beta1);
+    a.beta2 = (float)cfg->adam_beta2; a.one_minus_beta2 = (float)(1.0 - cfg->adam_beta2);
+    a.eps = (float)cfg->adam_eps;
+    a.sigma = cfg->sigma; a.joint_w = cfg->joint_loss_weight; a.pose_prior_w = cfg->pose_prior_weight;
+    a.angle_w = cfg->angle_prior_weight; a.shape_w = cfg->shape_prior_weight; a.preserve_w = cfg->pose_preserve_weight;
+    a.freeze_betas = cfg->freeze_betas ? 1 : 0;
+    a.num_betas_prior = cfg->num_betas_prior > 0 ? (cfg->num_betas_prior < NB ? cfg->num_betas_prior : NB) : NB;
+    a.opt_mask = cfg->optimize_mask & 15;
+    HIP_TRY(k2b::launch_fit_tree(a, (hipStream_t)stream));
+    return K2B_OK;
+}
+}  // namespace
 
 int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
                   const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
@@ -480,8 +673,13 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
                   float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream) {
     k2b_model* model = const_cast<k2b_model*>(model_c);
     if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
-    if (!model->fit_ok) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: %s", model->fit_why.c_str());
-    if (prior->D != 3 * (model->J - 1)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: prior dim %d != 3*(J-1)", prior->D);
+    const int pose_dims_all = 3 * (model->J - 1);
+    const int prior_dims = cfg->prior_pose_dims > 0 ? cfg->prior_pose_dims : (prior->D < pose_dims_all ? prior->D : pose_dims_all);
+    const bool small_tree = model->fit_ok && prior->D == pose_dims_all && prior_dims == pose_dims_all &&
+                            (cfg->num_betas_prior == 0 || cfg->num_betas_prior == model->NB);
+    if (!small_tree)
+        return fit_tree(model, const_cast<k2b_prior*>(prior), cfg, prior_dims, B, K, model_joint_index, j3d, conf, go_in, bp_in, be_in, tr_in,
+                        preserve, tr_prior, go_out, bp_out, be_out, tr_out, loss_out, grad_out, stream);
     if (B < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_frames=%d", B);
     if (K < 1 || K > model->J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_targets=%d out of range", K);
     if (!model_joint_index) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index is NULL");
@@ -510,36 +708,8 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
         a.angle_sign[i] = cfg->angle_prior_sign[i];
     }
 
-    // Adam bias terms in double, exactly as torch/optim/adam.py computes them in Python floats
     float2* coef = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(model->mu);
-        const auto key = std::make_tuple((int)cfg->num_iters, cfg->step_size, cfg->adam_beta1, cfg->adam_beta2);
-        auto it = model->adam_tables.find(key);
-        if (it == model->adam_tables.end()) {
-            std::vector<float2> h(cfg->num_iters);
-            const double lr = cfg->step_size, b1 = cfg->adam_beta1, b2 = cfg->adam_beta2;
-            for (int t = 1; t <= cfg->num_iters; ++t) {
-                const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
-                h[t - 1] = make_float2((float)(lr / bc1), (float)std::sqrt(bc2));
-            }
-            constexpr size_t kMaxAdamTables = 64;
-            if (model->adam_tables.size() >= kMaxAdamTables) {       // evict the least recently used table
-                auto victim = model->adam_tables.begin();
-                for (auto jt = model->adam_tables.begin(); jt != model->adam_tables.end(); ++jt)
-                    if (jt->second.last_use < victim->second.last_use) victim = jt;
-                HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // a launch in flight may still read it
-                HIP_TRY(hipDeviceSynchronize());
-                HIP_TRY(hipFree(victim->second.dev));
-                model->adam_tables.erase(victim);
-            }
-            HIP_TRY(upload(&coef, h.data(), h.size()));
-            model->adam_tables[key] = {coef, ++model->adam_clock};
-        } else {
-            coef = it->second.dev;
-            it->second.last_use = ++model->adam_clock;
-        }
-    }
+    if (const int rc = adam_table(model, cfg, (hipStream_t)stream, &coef); rc != K2B_OK) return rc;
 
     a.dt = model->dt; a.dd = model->dd; a.lane_tab = model->tree;
     // global transforms are only needed down to the deepest targeted joint: 2^rounds > its depth

@@ -1,0 +1,319 @@
+// k2b_fit_tree.hip — fused fit for LARGE kinematic trees (25..64 joints: SMPL-H / SMPL-X) on gfx950.
+//
+// Same work as k2b_fit.hip (all Adam iterations of `WorldSpaceFitter.fit_frame`'s Adam branch, reference
+// keypoints2body/core/fitters/world_space.py:248-256, in one launch; nothing touches HBM inside the loop), for
+// models whose tree does not fit the 24-lane layout of that kernel:
+//   * one wavefront per frame, lane l = the l-th joint in DFS pre-order (every subtree a contiguous lane range);
+//     the optimiser state lives in the lane of its joint: theta_j (3), and on the low lanes the shape
+//     coefficients (betas | expression, one per lane) and the translation (lanes 0..2);
+//   * forward kinematics level by level with cross-lane moves (12 ds_bpermute per level, depth <= 15), the
+//     analytic backward exactly as in k2b_fit.hip: subtree sums of the joint-loss gradient g and of p x g as
+//     differences of ONE inclusive prefix scan (double precision: the differences must not cancel), the torque
+//     about each joint pulled back to its rotation vector with the closed-form left Jacobian of SO(3);
+//   * max-mixture pose prior (core/prior.py:182-195) over the first D_v <= 64 body-pose dimensions, lane i = prior
+//     dimension i.  The reference's SMPL-X handling feeds a 69-D body pose to a 69-D mixture although smplx's
+//     SMPL-X has 63 body dimensions (SURVEY.md note N3); this engine defines it as the 69-D mixture evaluated
+//     at [theta_body(63) | 0 x 6].  With the six padded dimensions constant the quadratic form folds, ON THE HOST,
+//     into a D_v-dimensional one:  q_m = d^T A_m d + 2 b_m^T d + c_m  (d = theta_v - mu_v; A = P_vv, b = P_vc d_c,
+//     c = d_c^T P_cc d_c, d_c = -mu_c), and y' = A theta_v + h (h = b - A mu_v) is both the gradient of 0.5 q and,
+//     through q = d.(y' + b) + c, the value.  The eight components' A (8 x 16 KiB) are resident in LDS, shared by the
+//     8 frames of a workgroup; theta_v is broadcast from scalar registers (v_readlane), so a component costs 16
+//     ds_read_b128 + 64 FMAs per lane.
+// Loss terms, Adam arithmetic and the "loss of the last iteration before its step" convention are those of
+// k2b_fit.hip (oracle: oracle/fit_torch.py; goldens: tests/golden/smplx_fit_*.npz).
+#include "k2b_internal.h"
+
+namespace k2b {
+
+namespace {
+
+constexpr int TW = 8;                    // frames (waves) per workgroup
+constexpr int TMG = kPriorMaxGauss;      // 8 mixture components
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+
+// inclusive prefix sum over the 64 lanes, in double (Hillis-Steele; six rounds)
+__device__ __forceinline__ double wave_scan(float v, int lane) {
+    double s = (double)v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(s, off, 64);
+        if (lane >= off) s += o;
+    }
+    return s;
+}
+__device__ __forceinline__ double shfl64(double v, int src) { return __shfl(v, src, 64); }
+
+template <int NS>                        // capacity for shape coefficients (betas | expression): 16 or 32
+__global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tlds[];
+    // [M][16][64][4] A | [M][64] h | [M][64] b | [M][64] mu
+    float* const sA = tlds;
+    float* const sH = sA + TMG * 16 * 64 * 4;
+    float* const sB = sH + TMG * 64;
+    float* const sMu = sB + TMG * 64;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int J = a.num_joints, NB = a.num_shape, M = a.num_gauss, Dv = a.prior_dims;
+    const int fr_raw = blockIdx.x * TW + wave;
+    const bool frame_ok = fr_raw < a.num_frames;
+    const int fr = frame_ok ? fr_raw : a.num_frames - 1;           // idle waves shadow the last frame and write nothing
+
+    // ---- prior image -> LDS (whole workgroup) ---------------------------------------------------------------------------
+    for (int i = threadIdx.x; i < M * 16 * 64; i += 64 * TW)
+        reinterpret_cast<float4*>(sA)[i] = reinterpret_cast<const float4*>(a.pA)[i];
+    for (int i = threadIdx.x; i < M * 64; i += 64 * TW) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
+    __syncthreads();
+
+    // ---- per-lane constants ---------------------------------------------------------------------------------------------
+    const int* tb = a.tab + lane * 8;
+    const int joint = tb[0], plane = tb[1], ssize = tb[2], depth = tb[3];
+    const int psrc = tb[4], pcomp = tb[5];       // prior layout: lane i takes theta[pcomp] of lane psrc (or -1)
+    const int pd0 = tb[6];                       // tree layout: this joint's first prior dimension (or -1)
+    const bool isJ = lane < J;
+    const float dtx = a.dt[lane * 3], dty = a.dt[lane * 3 + 1], dtz = a.dt[lane * 3 + 2];
+    float dd[3][NS];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) dd[c][k] = k < NB ? a.dd[(lane * 3 + c) * 32 + k] : 0.f;
+
+    // target of this joint
+    const int tk = isJ ? a.lane_target[lane] : -1;
+    float ty0 = 0.f, ty1 = 0.f, ty2 = 0.f, wconf = 0.f;
+    if (tk >= 0) {
+        const float* y = a.j3d + ((size_t)fr * a.num_targets + tk) * 3;
+        ty0 = y[0]; ty1 = y[1]; ty2 = y[2];
+        const float cf = a.conf ? a.conf[(a.conf_per_frame ? (size_t)fr * a.num_targets : 0) + tk] : 1.0f;
+        wconf = (a.joint_w * a.joint_w) * (cf * cf);
+    }
+    const float s2 = a.sigma * a.sigma;
+
+    // ---- parameters and Adam state -----------------------------------------------------------------------------------------
+    const int D = 3 * (J - 1);
+    float th[3] = {0.f, 0.f, 0.f};
+    if (isJ) {
+        const float* src = joint == 0 ? a.go_in + (size_t)fr * 3 : a.bp_in + (size_t)fr * D + 3 * (joint - 1);
+        th[0] = src[0]; th[1] = src[1]; th[2] = src[2];
+    }
+    float sh = lane < NB ? a.be_in[(size_t)fr * NB + lane] : 0.f;
+    float tr = lane < 3 ? a.tr_in[(size_t)fr * 3 + lane] : 0.f;
+    float mth[3] = {0.f, 0.f, 0.f}, vth[3] = {0.f, 0.f, 0.f}, msh = 0.f, vsh = 0.f, mtr = 0.f, vtr = 0.f;
+    // which parameters the optimiser owns
+    const bool opt_th = isJ && (joint == 0 ? (a.opt_mask & 1) : (a.opt_mask & 2));
+    const bool opt_sh = lane < NB && (a.opt_mask & 4) && !(a.freeze_betas && lane < a.num_betas_prior);
+    const bool opt_tr = lane < 3 && (a.opt_mask & 8);
+    // prior-layout constants (lane i = prior dimension i)
+    const bool isP = lane < Dv;
+    const float pres0 = isP ? (a.preserve ? a.preserve[(size_t)fr * D + lane] : a.bp_in[(size_t)fr * D + lane]) : 0.f;
+    float ang_s = 0.f;                           // sign of the bending prior on this dimension (0: none)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (a.angle_index[i] == lane && isP) ang_s = a.angle_sign[i];
+    const float wpp = a.pose_prior_w * a.pose_prior_w, wang = a.angle_w * a.angle_w, wsh = a.shape_w * a.shape_w,
+                wpr = a.preserve_w * a.preserve_w;
+
+    float loss_total = 0.f;
+    float gth[3] = {0.f, 0.f, 0.f}, gsh = 0.f, gtr = 0.f;
+
+    for (int it = 0; it < a.num_iters; ++it) {
+        // ---- rest offset from the parent: d = dt + dd . shape -------------------------------------------------------------
+        float dx = dtx, dy = dty, dz = dtz;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (k < NB) {
+                const float sk = read_lane(sh, k);
+                dx = fmaf(dd[0][k], sk, dx); dy = fmaf(dd[1][k], sk, dy); dz = fmaf(dd[2][k], sk, dz);
+            }
+        }
+        const Rodrigues rod = rodrigues_fwd({th[0], th[1], th[2]});
+
+        // ---- forward kinematics, level by level --------------------------------------------------------------------------------
+        Mat3 Rg = rod.R;
+        Vec3 pg = {dx, dy, dz};
+        for (int lev = 1; lev <= a.max_depth; ++lev) {
+            Mat3 pR;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pR.m[i] = shfl(Rg.m[i], plane);
+            const Vec3 pp = {shfl(pg.x, plane), shfl(pg.y, plane), shfl(pg.z, plane)};
+            if (depth == lev) {
+                pg = mul(pR, Vec3{dx, dy, dz}) + pp;
+                Rg = mul(pR, rod.R);
+            }
+        }
+
+        // ---- joint term (losses.py:6-10,49-51) ---------------------------------------------------------------------------------------
+        const float t0 = read_lane(tr, 0), t1 = read_lane(tr, 1), t2 = read_lane(tr, 2);
+        float lj = 0.f;
+        Vec3 g = {0.f, 0.f, 0.f};
+        if (tk >= 0) {
+            const float ex = pg.x + t0 - ty0, ey = pg.y + t1 - ty1, ez = pg.z + t2 - ty2;
+            const float x2 = ex * ex, y2 = ey * ey, z2 = ez * ez;
+            const float qx = s2 + x2, qy = s2 + y2, qz = s2 + z2;
+            lj = wconf * ((s2 * x2) / qx + (s2 * y2) / qy + (s2 * z2) / qz);
+            const float k2 = 2.f * wconf * (s2 * s2);
+            g = {k2 * ex / (qx * qx), k2 * ey / (qy * qy), k2 * ez / (qz * qz)};
+        }
+
+        // ---- subtree sums: S = sum g, Mo = sum p x g over the subtree of every joint ----------------------------------------------------
+        const Vec3 pxg = cross(pg, g);
+        const float v6[6] = {g.x, g.y, g.z, pxg.x, pxg.y, pxg.z};
+        float sub[6];
+        const int hi = lane + ssize - 1 < 63 ? lane + ssize - 1 : 63, lo = lane > 0 ? lane - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double pre = wave_scan(isJ ? v6[i] : 0.f, lane);
+            const double up = shfl64(pre, hi), dn = shfl64(pre, lo);
+            sub[i] = (float)(up - (lane > 0 ? dn : 0.0));
+        }
+        const Vec3 S = {sub[0], sub[1], sub[2]};
+        const Vec3 torque = Vec3{sub[3], sub[4], sub[5]} - cross(pg, S);
+        // pull back: Rg = Rgp R  =>  Rgp^T v = R (Rg^T v)
+        const Vec3 w = mul(rod.R, mulT(Rg, torque));
+        const Vec3 gd = mul(rod.R, mulT(Rg, S));                    // d loss / d (rest offset of this joint)
+        {
+            const float a1 = rod.s * rod.inv_angle, a3 = (1.0f - rod.c) * rod.inv_angle;
+            const float uw = rod.u.x * w.x + rod.u.y * w.y + rod.u.z * w.z;
+            const float a2uw = (1.0f - a1) * uw;
+            const Vec3 uxw = cross(rod.u, w);
+            gth[0] = isJ ? a1 * w.x + a2uw * rod.u.x - a3 * uxw.x : 0.f;
+            gth[1] = isJ ? a1 * w.y + a2uw * rod.u.y - a3 * uxw.y : 0.f;
+            gth[2] = isJ ? a1 * w.z + a2uw * rod.u.z - a3 * uxw.z : 0.f;
+        }
+        // translation: the whole tree's force (root subtree = everything), one component per lane 0..2
+        {
+            const float s0 = read_lane(S.x, 0), s1 = read_lane(S.y, 0), s2r = read_lane(S.z, 0);
+            gtr = lane == 0 ? s0 : (lane == 1 ? s1 : s2r);
+        }
+        // shape coefficients through the rest offsets: g_k = sum_l gd_l . dd_l[:, k]  (+ shape prior on the betas)
+        gsh = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (k < NB) {
+                const float part = isJ ? gd.x * dd[0][k] + gd.y * dd[1][k] + gd.z * dd[2][k] : 0.f;
+                const float tot = wave_sum(part);
+                if (lane == k) gsh = tot;
+            }
+        }
+        float lsh = 0.f;
+        if (lane < a.num_betas_prior) { lsh = wsh * sh * sh; gsh += 2.f * wsh * sh; }
+
+        // ---- priors on the body pose, prior layout (lane i = prior dimension i) ----------------------------------------------------------
+        float thv;
+        {
+            const float c0 = shfl(th[0], psrc < 0 ? 0 : psrc), c1 = shfl(th[1], psrc < 0 ? 0 : psrc), c2 = shfl(th[2], psrc < 0 ? 0 : psrc);
+            thv = psrc < 0 ? 0.f : (pcomp == 0 ? c0 : (pcomp == 1 ? c1 : c2));
+        }
+        float gv = 0.f, lv = 0.f;                // gradient and loss contributions in prior layout
+        float lpr = 0.f;
+        if (wpp > 0.f) {
+            float y[TMG];
+#pragma unroll
+            for (int m = 0; m < TMG; ++m) y[m] = m < M ? sH[m * 64 + lane] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float q0 = read_lane(thv, 4 * c), q1 = read_lane(thv, 4 * c + 1), q2 = read_lane(thv, 4 * c + 2),
+                            q3 = read_lane(thv, 4 * c + 3);
+#pragma unroll
+                for (int m = 0; m < TMG; ++m) {
+                    if (m < M) {
+                        const floatx4 A4 = *reinterpret_cast<const floatx4*>(sA + ((m * 16 + c) * 64 + lane) * 4);
+                        y[m] = fmaf(A4[0], q0, fmaf(A4[1], q1, fmaf(A4[2], q2, fmaf(A4[3], q3, y[m]))));
+                    }
+                }
+            }
+            float best = 3.0e38f;
+            int bm = 0;
+#pragma unroll
+            for (int m = 0; m < TMG; ++m) {
+                if (m < M) {
+                    const float dq = isP ? (thv - sMu[m * 64 + lane]) * (y[m] + sB[m * 64 + lane]) : 0.f;
+                    const float ell = 0.5f * wave_sum(dq) + a.pcl[m];
+                    if (ell < best) { best = ell; bm = m; }      // first minimum wins, as torch.min does
+                }
+            }
+            float yb = y[0];
+#pragma unroll
+            for (int m = 1; m < TMG; ++m) yb = bm == m ? y[m] : yb;
+            gv = isP ? wpp * yb : 0.f;
+            lpr = wpp * best;
+        }
+        if (ang_s != 0.f) {                       // losses.py:13-21,54: w^2 exp(s theta)^2
+            const float e = __expf(ang_s * thv);
+            lv += wang * e * e;
+            gv += 2.f * wang * ang_s * e * e;
+        }
+        if (wpr > 0.f && isP) {
+            const float df = thv - pres0;
+            lv += wpr * df * df;
+            gv += 2.f * wpr * df;
+        }
+        // back to the tree layout: joint lane l takes dimensions pd0 .. pd0 + 2
+        {
+            const int s0i = pd0 < 0 ? 0 : pd0;
+            const float a0 = shfl(gv, s0i), a1 = shfl(gv, s0i + 1 < 64 ? s0i + 1 : 63), a2 = shfl(gv, s0i + 2 < 64 ? s0i + 2 : 63);
+            if (pd0 >= 0) { gth[0] += a0; gth[1] += a1; gth[2] += a2; }
+        }
+        loss_total = wave_sum(lj + lsh + lv) + lpr;
+
+        // ---- Adam (torch.optim.Adam, single-tensor path; bias terms from the host table) ----------------------------------------------
+        const float2 co = a.adam_coef[it];
+        auto adam = [&](float& x, float& mm, float& vv, float gi, bool on) {
+            if (!on) return;
+            mm = mm + a.one_minus_beta1 * (gi - mm);
+            vv = vv * a.beta2 + a.one_minus_beta2 * gi * gi;
+            const float denom = fast_sqrt(vv) * fast_rcp(co.y) + a.eps;
+            x = x - co.x * (mm * fast_rcp(denom));
+        };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) adam(th[c], mth[c], vth[c], gth[c], opt_th);
+        adam(sh, msh, vsh, gsh, opt_sh);
+        adam(tr, mtr, vtr, gtr, opt_tr);
+    }
+
+    if (!frame_ok) return;
+    if (isJ) {
+        float* dst = joint == 0 ? a.go_out + (size_t)fr * 3 : a.bp_out + (size_t)fr * D + 3 * (joint - 1);
+        dst[0] = th[0]; dst[1] = th[1]; dst[2] = th[2];
+    }
+    if (lane < NB) a.be_out[(size_t)fr * NB + lane] = sh;
+    if (lane < 3) a.tr_out[(size_t)fr * 3 + lane] = tr;
+    if (lane == 0 && a.loss_out) a.loss_out[fr] = loss_total;
+    if (a.grad_out) {
+        const int P = 3 + D + NB + 3;
+        float* go = a.grad_out + (size_t)fr * P;
+        if (isJ) {
+            float* dst = joint == 0 ? go : go + 3 + 3 * (joint - 1);
+            dst[0] = opt_th ? gth[0] : 0.f; dst[1] = opt_th ? gth[1] : 0.f; dst[2] = opt_th ? gth[2] : 0.f;
+        }
+        if (lane < NB) go[3 + D + lane] = opt_sh ? gsh : 0.f;
+        if (lane < 3) go[3 + D + NB + lane] = opt_tr ? gtr : 0.f;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream) {
+    if (a.num_frames <= 0) return hipSuccess;
+    if (a.num_joints > 64 || a.num_shape > 32 || a.prior_dims > 64 || a.num_gauss > TMG) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(TMG * 16 * 64 * 4 + 3 * TMG * 64) * sizeof(float);
+    const dim3 grid((a.num_frames + TW - 1) / TW), block(64 * TW);
+    hipError_t e;
+#define K2B_TREE(NS_)                                                                                                  \
+    do {                                                                                                               \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            e = hipFuncSetAttribute((const void*)k2b_fit_tree_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                             \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k2b_fit_tree_kernel<NS_>), grid, block, lds, stream, a);                                   \
+    } while (0)
+    if (a.num_shape <= 16) K2B_TREE(16); else K2B_TREE(32);
+#undef K2B_TREE
+    return hipGetLastError();
+}
+
+}  // namespace k2b

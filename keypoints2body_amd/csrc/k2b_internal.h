@@ -10,7 +10,8 @@ namespace k2b {
 constexpr int kFitJoints = 24;      // joints of the tree the fused fit kernel is built for (SMPL)
 constexpr int kPriorDim = 69;       // 3 * (kFitJoints - 1)
 constexpr int kPriorMaxGauss = 8;   // mixture components resident in LDS
-constexpr int kMaxBetas = 16;
+constexpr int kMaxBetas = 16;       // shape coefficients of the 24-joint fused fit kernel
+constexpr int kMaxShape = 32;       // shape coefficients (betas | expression) of the LBS kernels and the tree fit kernel
 constexpr int kFitMaxWaves = 8;     // frames (waves) per workgroup
 constexpr int kMaxJoints = 64;
 constexpr int kMaxRounds = 4;       // pointer-doubling rounds: tree depth < 2^4
@@ -62,6 +63,38 @@ struct FitArgs {
 };
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);
+
+// Kernel arguments of the fused fit for large trees (k2b_fit_tree.hip: 25..64 joints, SMPL-H / SMPL-X).
+struct FitTreeArgs {
+    // model (device), indexed by LANE (DFS pre-order of the kinematic tree)
+    const float* dt;            // [64][3]      rest offset from the parent at shape 0 (root: its rest joint)
+    const float* dd;            // [64][3][32]  the same for the shape directions, zero padded
+    const int* tab;             // [64][8]: joint, parent lane, subtree size, depth, prior source lane, prior source
+                                //          component, first prior dimension of this joint (-1: none), unused
+    int num_joints, num_shape, max_depth;
+    // prior (device): the mixture folded to its first prior_dims <= 64 dimensions (see k2b_fit_tree.hip)
+    const float* pA;            // [M][16][64][4]   A_m[i][4 c + k] at ((m 16 + c) 64 + i) 4 + k
+    const float *ph, *pb, *pmu; // [M][64]          h = b - A mu, b, mu
+    const float* pcl;           // [M]              0.5 c_m - log(nll weight)
+    int num_gauss, prior_dims;
+    // call
+    int num_frames, num_targets;
+    int lane_target[64];        // target index fitted by the joint of lane l, or -1
+    const float* j3d;
+    const float* conf;
+    int conf_per_frame;
+    const float *go_in, *bp_in, *be_in, *tr_in, *preserve;
+    float *go_out, *bp_out, *be_out, *tr_out, *loss_out, *grad_out;
+    const float2* adam_coef;    // [num_iters] {lr / (1 - b1^t), sqrt(1 - b2^t)}
+    int num_iters;
+    float one_minus_beta1, beta2, one_minus_beta2, eps;
+    float sigma, joint_w, pose_prior_w, angle_w, shape_w, preserve_w;
+    int freeze_betas, num_betas_prior;   // the shape prior and freeze_betas apply to the first num_betas_prior coefficients
+    int opt_mask;               // bit 0 global_orient, 1 body_pose, 2 shape coefficients, 3 transl
+    int angle_index[4];
+    float angle_sign[4];
+};
+hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream);
 
 // LBS operands are f16 hi/lo pairs in MFMA fragment order: [k-step][row][16 halfs].
 typedef _Float16 k2b_half;

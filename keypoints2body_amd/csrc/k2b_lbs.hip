@@ -70,18 +70,18 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         const float* src = j == 0 ? a.go + (size_t)f * 3 : a.bp + (size_t)f * 3 * (J - 1) + 3 * (j - 1);
         th = {src[0], src[1], src[2]};
         par = a.parents[j];
-        float beta[kMaxBetas];
+        float beta[kMaxShape];
 #pragma unroll
-        for (int k = 0; k < kMaxBetas; ++k) beta[k] = k < NB ? a.be[(size_t)f * NB + k] : 0.f;
+        for (int k = 0; k < kMaxShape; ++k) beta[k] = k < NB ? a.be[(size_t)f * NB + k] : 0.f;
         float e[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float dir[kMaxBetas];
+            float dir[kMaxShape];
 #pragma unroll
-            for (int k = 0; k < kMaxBetas; ++k) dir[k] = k < NB ? a.j_dirs[(j * 3 + c) * NB + k] : 0.f;
+            for (int k = 0; k < kMaxShape; ++k) dir[k] = k < NB ? a.j_dirs[(j * 3 + c) * NB + k] : 0.f;
             float s = a.j_template[j * 3 + c];
 #pragma unroll
-            for (int k = 0; k < kMaxBetas; ++k) s += dir[k] * beta[k];      // same order of additions as before
+            for (int k = 0; k < kMaxShape; ++k) s += dir[k] * beta[k];      // same order of additions as before
             e[c] = s;
         }
         Jj = {e[0], e[1], e[2]};
@@ -510,8 +510,6 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     // The per-lane LDS offsets are re-derived from the lane id at the start of each phase (behind an opaque copy, so
     // that they are not hoisted out of the tile loop): eight registers less alive across the other phase.
     auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    auto ftile_c = [&](int fgx, int t) { const int x = fgx * 4 + t; return x < ftiles ? x : ftiles - 1; };
-    auto vtile_c = [&](int vgx, int t) { const int x = vgx * 4 + t; return x < vtiles ? x : vtiles - 1; };
     const int lane8 = lane * 8;                       // halfs: this lane's 16 bytes of a 1 KiB piece
 
     // ---- roles -----------------------------------------------------------------------------------------------------

@@ -19,18 +19,34 @@ import torch
 from .. import native, synthetic
 
 
+# smplx SMPL-X full pose behind the root: body 63 | jaw | left eye | right eye | left hand 45 | right hand 45 (joints 1..54)
+SMPLX_POSE_FIELDS = (("body_pose", 63), ("jaw_pose", 3), ("leye_pose", 3), ("reye_pose", 3), ("left_hand_pose", 45),
+                     ("right_hand_pose", 45))
+
+
 class BodyModel:
-    """SMPL-family model on one MI355X.  No CPU path: construction needs a HIP device."""
+    """SMPL-family model on one MI355X.  No CPU path: construction needs a HIP device.
+
+    55-joint models are SMPL-X (``model_type == "smplx"``): the kernels see ONE pose vector of all non-root joints
+    (162 values) and ONE vector of shape coefficients (betas | expression); ``pack_pose`` / ``pack_shape`` /
+    ``unpack`` translate from and to smplx's keyword arguments (hands as full axis-angle poses, ``use_pca=False``)."""
 
     NUM_BODY_JOINTS = 23
+    NUM_HAND_JOINTS = 15
 
     def __init__(self, v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents,
                  extra_vertex_ids=None, device=None, model_type: str = "smpl"):
         self.native = native.NativeModel(v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents,
                                          extra_vertex_ids, device=device)
         self.device = self.native.device
-        self.model_type = model_type
-        self.num_betas = self.native.num_betas
+        self.model_type = "smplx" if self.native.num_joints == 55 else model_type
+        self.num_shape = self.native.num_betas                     # everything the shape blend takes
+        if self.model_type == "smplx":
+            self.NUM_BODY_JOINTS = 21
+            self.num_betas = 10 if self.num_shape > 10 else self.num_shape
+            self.num_expression_coeffs = self.num_shape - self.num_betas
+        else:
+            self.num_betas = self.num_shape
         self.num_joints = self.native.num_joints
         self.num_vertices = self.native.num_vertices
         self.parents = torch.as_tensor(np.asarray(parents), dtype=torch.long)
@@ -42,6 +58,47 @@ class BodyModel:
         c = synthetic.make_body_model(seed)
         return cls(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents,
                    c.extra_vertex_ids, device=device)
+
+    @classmethod
+    def synthetic_x(cls, seed: int = 0, device=None) -> "BodyModel":
+        """SMPL-X-shaped synthetic model (55 joints, V = 10475, 10 betas + 10 expression coefficients)."""
+        c = synthetic.make_body_model_x(seed)
+        return cls(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents,
+                   c.extra_vertex_ids, device=device, model_type="smplx")
+
+    # -- SMPL-X packing ---------------------------------------------------------------------
+    def pack_pose(self, B: int, **kw) -> torch.Tensor:
+        """(B, 3 (J - 1)) pose of all non-root joints from smplx keyword arguments (missing ones are zero)."""
+        if self.model_type != "smplx":
+            return self._as_dev(kw.get("body_pose"), 3 * (self.num_joints - 1)) if kw.get("body_pose") is not None \
+                else torch.zeros((B, 3 * (self.num_joints - 1)), dtype=torch.float32, device=self.device)
+        parts = []
+        for name, cols in SMPLX_POSE_FIELDS:
+            x = kw.get(name)
+            t = self._as_dev(x, cols) if x is not None else torch.zeros((B, cols), dtype=torch.float32, device=self.device)
+            parts.append(t.expand(B, -1) if t.shape[0] != B else t)
+        return torch.cat(parts, dim=1).contiguous()
+
+    def pack_shape(self, B: int, betas=None, expression=None) -> torch.Tensor:
+        z = lambda c: torch.zeros((B, c), dtype=torch.float32, device=self.device)
+        if self.model_type != "smplx":
+            return self._as_dev(betas, self.num_shape) if betas is not None else z(self.num_shape)
+        be = self._as_dev(betas, self.num_betas) if betas is not None else z(self.num_betas)
+        ex = self._as_dev(expression, self.num_expression_coeffs) if expression is not None else z(self.num_expression_coeffs)
+        be, ex = (t.expand(B, -1) if t.shape[0] != B else t for t in (be, ex))
+        return torch.cat((be, ex), dim=1).contiguous()
+
+    def unpack(self, pose: torch.Tensor, shape: torch.Tensor) -> dict:
+        """Inverse of pack_pose / pack_shape: smplx field name -> tensor."""
+        if self.model_type != "smplx":
+            return {"body_pose": pose, "betas": shape}
+        out, o = {}, 0
+        for name, cols in SMPLX_POSE_FIELDS:
+            out[name] = pose[:, o:o + cols].contiguous()
+            o += cols
+        out["betas"] = shape[:, :self.num_betas].contiguous()
+        out["expression"] = shape[:, self.num_betas:].contiguous()
+        return out
 
     @classmethod
     def from_smplx(cls, model, device=None) -> "BodyModel":
@@ -76,19 +133,25 @@ class BodyModel:
 
     def __call__(self, global_orient=None, body_pose=None, betas=None, transl=None,
                  return_full_pose: bool = False, return_verts: bool = True, **unused):
-        given = [x for x in (global_orient, body_pose, betas, transl) if x is not None]
+        extra = {k: unused.get(k) for k in ("jaw_pose", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose", "expression")}
+        given = [x for x in (global_orient, body_pose, betas, transl, *extra.values()) if x is not None]
         B = max((int(torch.as_tensor(x).reshape(-1, torch.as_tensor(x).shape[-1]).shape[0]) for x in given), default=1)
-        D = 3 * (self.num_joints - 1)
         zeros = lambda c: torch.zeros((B, c), dtype=torch.float32, device=self.device)
         go = self._as_dev(global_orient, 3) if global_orient is not None else zeros(3)
-        bp = self._as_dev(body_pose, D) if body_pose is not None else zeros(D)
-        be = self._as_dev(betas, self.num_betas) if betas is not None else zeros(self.num_betas)
+        if self.model_type == "smplx":
+            bp = self.pack_pose(B, body_pose=body_pose, **{k: v for k, v in extra.items() if k != "expression"})
+            be = self.pack_shape(B, betas, extra["expression"])
+        else:
+            D = 3 * (self.num_joints - 1)
+            bp = self._as_dev(body_pose, D) if body_pose is not None else zeros(D)
+            be = self._as_dev(betas, self.num_betas) if betas is not None else zeros(self.num_betas)
         tr = self._as_dev(transl, 3) if transl is not None else None
         go, bp, be = (t.expand(B, -1).contiguous() if t.shape[0] != B else t for t in (go, bp, be))
         if tr is not None and tr.shape[0] != B:
             tr = tr.expand(B, -1).contiguous()
         joints, verts = self.native.lbs(go, bp, be, tr, want_vertices=return_verts)
-        return SimpleNamespace(vertices=verts, joints=joints, betas=be, global_orient=go, body_pose=bp,
+        return SimpleNamespace(vertices=verts, joints=joints, betas=be[:, :self.num_betas], global_orient=go,
+                               body_pose=bp[:, :3 * self.NUM_BODY_JOINTS],
                                full_pose=torch.cat((go, bp), dim=1) if return_full_pose else None)
 
     forward = __call__

@@ -52,6 +52,8 @@ class FitConfigC(C.Structure):
         ("optimize_mask", C.c_int32),
         ("transl_prior_weight", C.c_float),
         ("debug_launch_shape", C.c_int32),
+        ("prior_pose_dims", C.c_int32),
+        ("num_betas_prior", C.c_int32),
     ]
 
 

@@ -60,6 +60,33 @@ _REST_JOINTS = np.array(
     dtype=np.float64,
 )
 
+# SMPL-X kinematic tree (55 joints, smplx numbering): 0-21 body, 22 jaw, 23/24 eyes (children of the head, 15),
+# 25-39 left hand (index, middle, pinky, ring, thumb: three joints each, rooted at the left wrist, 20), 40-54 right hand.
+SMPLX_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15,
+     20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+     21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53],
+    dtype=np.int32,
+)
+
+
+def _smplx_rest_joints() -> np.ndarray:
+    """Plausible T-pose skeleton of the 55-joint tree: the SMPL body joints 0-21, jaw and eyes on the head, five
+    three-joint fingers fanning out of either wrist (hand-written, not a licensed template)."""
+    rest = np.zeros((55, 3), dtype=np.float64)
+    rest[:22] = _REST_JOINTS[:22]
+    head = rest[15]
+    rest[22] = head + np.array([0.0, -0.02, 0.05])       # jaw
+    rest[23] = head + np.array([0.03, 0.06, 0.08])       # left eye
+    rest[24] = head + np.array([-0.03, 0.06, 0.08])      # right eye
+    for side, wrist, first in ((1.0, 20, 25), (-1.0, 21, 40)):
+        for fi, (dy, dz) in enumerate(((0.012, 0.025), (0.014, 0.005), (0.004, -0.030), (0.010, -0.012), (-0.010, 0.035))):
+            base = rest[wrist] + np.array([side * 0.085, dy, dz])
+            for seg in range(3):
+                rest[first + 3 * fi + seg] = base + np.array([side * 0.028 * seg, -0.002 * seg, 0.0])
+    return rest
+
+
 _SQRT3 = 1.7320508075688772  # literal, so no libm sqrt is involved
 _MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -151,12 +178,20 @@ class SyntheticBodyModel:
         )
 
 
-def make_body_model(seed: int = 0, num_vertices: int = 6890, num_betas: int = 10) -> SyntheticBodyModel:
-    """Build the SMPL-shaped synthetic model (float32 arrays)."""
-    parents = SMPL_PARENTS.copy()
+def make_body_model_x(seed: int = 0, num_vertices: int = 10475, num_shape: int = 20, num_extra: int = 72) -> SyntheticBodyModel:
+    """SMPL-X-shaped synthetic model: V = 10475, 55 joints on the SMPL-X tree, 20 shape coefficients (10 betas | 10
+    expression coefficients, concatenated as smplx does), 486 pose-corrective rows, 55 + 72 = 127 output joints."""
+    return make_body_model(seed, num_vertices, num_shape, parents=SMPLX_PARENTS.copy(), rest=_smplx_rest_joints(),
+                           num_extra=num_extra)
+
+
+def make_body_model(seed: int = 0, num_vertices: int = 6890, num_betas: int = 10, parents=None, rest=None,
+                    num_extra: int = 21) -> SyntheticBodyModel:
+    """Build the SMPL-shaped synthetic model (float32 arrays); `parents` / `rest` select another tree."""
+    parents = SMPL_PARENTS.copy() if parents is None else parents
     J = parents.shape[0]
     V = num_vertices
-    rest = _REST_JOINTS
+    rest = _REST_JOINTS if rest is None else rest
 
     vid = np.arange(V)
     primary = vid % J                      # joint each vertex hangs on
@@ -204,7 +239,7 @@ def make_body_model(seed: int = 0, num_vertices: int = 6890, num_betas: int = 10
     P = 9 * (J - 1)
     posedirs = 0.002 * normalish(8, (P, 3 * V), seed)
 
-    extra_vertex_ids = ((331 + 311 * np.arange(21)) % V).astype(np.int32)
+    extra_vertex_ids = ((331 + 311 * np.arange(num_extra)) % V).astype(np.int32)
 
     return SyntheticBodyModel(
         v_template=v_template.astype(np.float32),
@@ -258,6 +293,31 @@ def make_poses(num_frames: int, seed: int = 0, num_betas: int = 10) -> Synthetic
         betas=(0.5 * normalish(32, (T, num_betas), seed)).astype(np.float32),
         transl=(1.0 * normalish(33, (T, 3), seed)).astype(np.float32),
     )
+
+
+@dataclass
+class SyntheticPosesX:
+    """Ground-truth SMPL-X parameters (smplx field names; hands as full axis-angle poses, use_pca=False)."""
+
+    global_orient: np.ndarray    # (T,3)
+    body_pose: np.ndarray        # (T,63)
+    jaw_pose: np.ndarray         # (T,3)
+    leye_pose: np.ndarray        # (T,3)
+    reye_pose: np.ndarray        # (T,3)
+    left_hand_pose: np.ndarray   # (T,45)
+    right_hand_pose: np.ndarray  # (T,45)
+    betas: np.ndarray            # (T,10)
+    expression: np.ndarray       # (T,10)
+    transl: np.ndarray           # (T,3)
+
+
+def make_poses_x(num_frames: int, seed: int = 0) -> SyntheticPosesX:
+    T = num_frames
+    f = lambda stream, cols, scale: (scale * normalish(stream, (T, cols), seed)).astype(np.float32)
+    return SyntheticPosesX(
+        global_orient=f(40, 3, 0.3), body_pose=f(41, 63, 0.2), jaw_pose=f(42, 3, 0.1), leye_pose=f(43, 3, 0.05),
+        reye_pose=f(44, 3, 0.05), left_hand_pose=f(45, 45, 0.15), right_hand_pose=f(46, 45, 0.15),
+        betas=f(47, 10, 0.5), expression=f(48, 10, 0.5), transl=f(49, 3, 1.0))
 
 
 def target_noise(num_frames: int, num_joints: int, seed: int = 0, scale: float = 0.005) -> np.ndarray:

@@ -63,7 +63,11 @@ class GMMPrior:
         self.nll_weights = torch.tensor(nll, dtype=torch.float32).unsqueeze(0)
 
     def per_component(self, pose: torch.Tensor) -> torch.Tensor:
-        """(B,69) -> (B,M) values 0.5 d^T P d - log(nll_w)  (prior.py:183-189)."""
+        """(B,69) -> (B,M) values 0.5 d^T P d - log(nll_w)  (prior.py:183-189).  A shorter pose (SMPL-X: 63 body
+        dimensions) is evaluated at [pose | 0 ...]: this engine's definition of the reference's inconsistent SMPL-X
+        handling (SURVEY.md note N3); the goldens apply the same padding in front of the reference's own prior."""
+        if pose.shape[1] < self.means.shape[1]:
+            pose = torch.nn.functional.pad(pose, (0, self.means.shape[1] - pose.shape[1]))
         diff = pose.unsqueeze(1) - self.means
         pd = torch.einsum("mij,bmj->bmi", [self.precisions, diff])
         quad = (pd * diff).sum(dim=-1)
@@ -175,6 +179,46 @@ def fit_world_adam(model, prior: GMMPrior, global_orient, body_pose, betas, tran
         out = model(global_orient=go, body_pose=bp, betas=be, transl=tr, return_full_pose=False)
     return FitOutput(go.detach(), bp.detach(), be.detach(), tr.detach(),
                      out.joints.detach(), out.vertices.detach(), last, trace)
+
+
+SMPLX_FIELDS = ("global_orient", "body_pose", "transl", "left_hand_pose", "right_hand_pose", "expression", "jaw_pose",
+                "leye_pose", "reye_pose", "betas")      # the optimiser's parameter list, world_space.py:215-229
+
+
+def fit_world_adam_smplx(model, prior: GMMPrior, params: dict, j3d, conf=None, *, num_iters: int, lr: float = 1e-2,
+                         seq_ind: int = 0, model_idx: Optional[Sequence[int]] = None, weights: Optional[FitWeights] = None,
+                         freeze_betas: bool = False, trace_iters: Sequence[int] = ()):
+    """Adam branch of ``WorldSpaceFitter.fit_frame`` for ``SMPLXData`` inputs (world_space.py:126-151: hands, expression,
+    jaw and eyes join the optimiser; 173-192: they are passed to the model; 202-212: the loss sees ``body_pose`` (63-D,
+    prior zero-padded to the mixture's 69 dimensions - see ``GMMPrior.per_component``), ``betas`` (not the expression)
+    and the model joints).  ``params``: dict of (B, .) tensors with the keys of ``SMPLX_FIELDS``.
+    Returns (dict of fitted tensors, per-frame loss of the last iteration before its step, joints, vertices, trace)."""
+    w = weights or FitWeights()
+    p = {k: params[k].clone().detach().requires_grad_(True) for k in SMPLX_FIELDS}
+    p["betas"].requires_grad = not freeze_betas
+    preserve = p["body_pose"].clone().detach()
+    K = j3d.shape[1]
+    conf = torch.ones(K) if conf is None else (conf[0] if conf.dim() == 2 else conf)
+    idx = list(range(K)) if model_idx is None else list(model_idx)
+
+    def per_frame():
+        out = model(**p)
+        return frame_losses(p["body_pose"], preserve, p["betas"], out.joints[:, idx, :], j3d, prior, conf, w,
+                            preserve_on=seq_ind > 0)
+
+    opt = torch.optim.Adam([v for k, v in p.items() if v.requires_grad], lr=lr, betas=(0.9, 0.999))
+    last, trace = None, {}
+    for it in range(1, num_iters + 1):
+        opt.zero_grad()
+        lf = per_frame()
+        lf.sum().backward()
+        opt.step()
+        last = lf.detach()
+        if it in trace_iters:
+            trace[it] = {k: v.detach().clone() for k, v in p.items()}
+    with torch.no_grad():
+        out = model(**p)
+    return {k: v.detach() for k, v in p.items()}, last, out.joints.detach(), out.vertices.detach(), trace
 
 
 def guess_init_transl(model, pose_aa, betas, j3d, root_model: int = 0, root_target: int = 0):

@@ -105,9 +105,18 @@ class TorchSMPL(torch.nn.Module):
         if betas is None:
             betas = torch.zeros(B, self.num_betas, dtype=dt, device=dev)
         full_pose = torch.cat([global_orient, body_pose], dim=1)
-        J = self.parents.shape[0]
+        joints, verts = self._lbs(full_pose, betas, transl)
+        return SimpleNamespace(
+            vertices=verts, joints=joints, betas=betas, global_orient=global_orient,
+            body_pose=body_pose, full_pose=full_pose if return_full_pose else None,
+        )
 
-        v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", betas, self.shapedirs)
+    def _lbs(self, full_pose, shape, transl):
+        """Steps 1-8 of the module docstring for a full pose (B, 3J) and all shape coefficients (B, NB)."""
+        B = full_pose.shape[0]
+        dev, dt = self.v_template.device, self.dtype
+        J = self.parents.shape[0]
+        v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", shape, self.shapedirs)
         joints_rest = torch.einsum("bik,ji->bjk", v_shaped, self.J_regressor)
         rot = batch_rodrigues(full_pose.reshape(-1, 3)).view(B, J, 3, 3)
         ident = torch.eye(3, dtype=dt, device=dev)
@@ -123,10 +132,40 @@ class TorchSMPL(torch.nn.Module):
         if transl is not None:
             joints = joints + transl.unsqueeze(1)
             verts = verts + transl.unsqueeze(1)
-        return SimpleNamespace(
-            vertices=verts, joints=joints, betas=betas, global_orient=global_orient,
-            body_pose=body_pose, full_pose=full_pose if return_full_pose else None,
-        )
+        return joints, verts
+
+
+class TorchSMPLX(TorchSMPL):
+    """SMPL-X duck type (smplx ``SMPLX.forward`` with ``use_pca=False``): 55 joints, full pose = [global_orient |
+    body_pose 63 | jaw | leye | reye | left_hand_pose 45 | right_hand_pose 45], shape = [betas | expression].
+    PARITY UNPINNED at the smplx boundary exactly like ``TorchSMPL``; in addition the reference's own SMPL-X handling
+    is inconsistent with smplx (SURVEY.md note N3), so the semantics here are this engine's definition."""
+
+    NUM_BODY_JOINTS = 21
+    NUM_HAND_JOINTS = 15
+
+    def __init__(self, consts, dtype=torch.float32, num_betas: int = 10):
+        super().__init__(consts, dtype)
+        self.num_shape = int(self.shapedirs.shape[2])
+        self.num_betas = num_betas
+        self.num_expression_coeffs = self.num_shape - num_betas
+
+    def forward(self, global_orient=None, body_pose=None, betas=None, transl=None, expression=None, jaw_pose=None,
+                leye_pose=None, reye_pose=None, left_hand_pose=None, right_hand_pose=None,
+                return_full_pose=False, return_verts=True, **_unused):
+        given = [x for x in (global_orient, body_pose, betas, expression, left_hand_pose) if x is not None]
+        B = max(x.shape[0] for x in given)
+        dev, dt = self.v_template.device, self.dtype
+        z = lambda x, c: torch.zeros(B, c, dtype=dt, device=dev) if x is None else x
+        parts = [z(global_orient, 3), z(body_pose, 63), z(jaw_pose, 3), z(leye_pose, 3), z(reye_pose, 3),
+                 z(left_hand_pose, 45), z(right_hand_pose, 45)]
+        if parts[1].shape[1] != 63:
+            raise ValueError(f"SMPL-X body_pose must be (B,63), got {tuple(parts[1].shape)}")
+        full_pose = torch.cat(parts, dim=1)
+        shape = torch.cat([z(betas, self.num_betas), z(expression, self.num_expression_coeffs)], dim=1)
+        joints, verts = self._lbs(full_pose, shape, transl)
+        return SimpleNamespace(vertices=verts, joints=joints, betas=shape[:, :self.num_betas], global_orient=parts[0],
+                               body_pose=parts[1], full_pose=full_pose if return_full_pose else None)
 
 
 # --------------------------------------------------------------------------

@@ -29,6 +29,29 @@ def oracle_model(seed: int = 0, double: bool = False):
 
 
 @functools.lru_cache(maxsize=None)
+def body_consts_x(seed: int = 0):
+    return synthetic.make_body_model_x(seed)
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_model_x(seed: int = 0, double: bool = False):
+    from oracle.smpl_torch import TorchSMPLX
+    return TorchSMPLX(body_consts_x(seed), dtype=torch.float64 if double else torch.float32)
+
+
+def load_smplx_case(name: str):
+    return dict(np.load(GOLDEN / f"smplx_fit_{name}.npz"))
+
+
+@functools.lru_cache(maxsize=None)
+def native_model_x(seed: int = 0):
+    from keypoints2body_amd.native import NativeModel
+    c = body_consts_x(seed)
+    return NativeModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents,
+                       c.extra_vertex_ids)
+
+
+@functools.lru_cache(maxsize=None)
 def gmm_fixture():
     return dict(np.load(GOLDEN / "gmm_synth.npz"))
 

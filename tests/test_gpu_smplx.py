@@ -1,0 +1,131 @@
+"""SMPL-X (BASELINE config 4: 55 joints, hands + face) on the GPU, through the C ABI.
+
+Pinned by ``tests/golden/smplx_fit_*.npz``: the REAL reference fitter driven with ``SMPLXData`` and the oracle's SMPL-X
+model (``oracle/gen_golden_smplx.py``; its 69-D prior evaluated at [body_pose | 0 x 6], the one definition this engine
+adds - SURVEY.md N3).  PARITY UNPINNED at the smplx boundary (the forward restates the published formulation), as for SMPL.
+Tolerances: fitted parameters 1e-4 abs (the north-star bar) at every recorded iteration, LBS 5e-6 m.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+PARAM_TOL = 1e-4
+CASES = ("all55_zero_init", "amass22_zero_init", "all55_followup_frozen")
+POSE_FIELDS = (("body_pose", 63), ("jaw_pose", 3), ("leye_pose", 3), ("reye_pose", 3), ("left_hand_pose", 45), ("right_hand_pose", 45))
+
+
+def pack(d, prefix, rows=slice(None)):
+    pose = np.concatenate([d[prefix + k][rows] for k, _ in POSE_FIELDS], axis=1)
+    shape = np.concatenate([d[prefix + "betas"][rows], d[prefix + "expression"][rows]], axis=1)
+    return d[prefix + "global_orient"][rows], pose, shape, d[prefix + "transl"][rows]
+
+
+def native_fit_x(d, num_iters):
+    from keypoints2body_amd import native
+    cfg = native.default_fit_config()
+    cfg.num_iters = int(num_iters)
+    cfg.pose_preserve_weight = 5.0 if int(d["seq_ind"]) > 0 else 0.0
+    cfg.freeze_betas = int(d["freeze_betas"])
+    cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
+    idx = [int(i) for i in d["target_model_indices"]] if d["target_model_indices"].size else list(range(22))
+    go, pose, shape, tr = map(H.cuda, pack(d, "init_"))
+    conf = H.cuda(d["conf"]) if int(d["has_conf"]) else None
+    return native.fit_world(H.native_model_x(), H.native_prior(), cfg, idx, H.cuda(d["j3d"]), conf, go, pose, shape, tr)
+
+
+def test_smplx_lbs_matches_oracle_forward():
+    from keypoints2body_amd import synthetic
+    B = 37                                              # ragged: one full and one partial 32-frame tile
+    p = synthetic.make_poses_x(B, seed=4)
+    t = lambda a: torch.tensor(np.asarray(a))
+    with torch.no_grad():
+        ref = H.oracle_model_x()(**{k: t(getattr(p, k)) for k in ("global_orient", "body_pose", "jaw_pose", "leye_pose", "reye_pose",
+                                                                   "left_hand_pose", "right_hand_pose", "betas", "expression", "transl")})
+    pose = np.concatenate([getattr(p, k) for k, _ in POSE_FIELDS], axis=1)
+    shape = np.concatenate([p.betas, p.expression], axis=1)
+    j, v = H.native_model_x().lbs(H.cuda(p.global_orient), H.cuda(pose), H.cuda(shape), H.cuda(p.transl))
+    assert tuple(j.shape) == (B, 127, 3) and tuple(v.shape) == (B, 10475, 3)
+    assert (v.cpu() - ref.vertices).abs().max() < 5e-6
+    assert (j.cpu() - ref.joints).abs().max() < 5e-6
+    j2, _ = H.native_model_x().lbs(H.cuda(p.global_orient), H.cuda(pose), H.cuda(shape), H.cuda(p.transl), want_vertices=False)
+    assert (j2.cpu() - ref.joints).abs().max() < 5e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_smplx_fit_matches_reference_golden(case):
+    d = H.load_smplx_case(case)
+    worst = 0.0
+    for ti, it in enumerate(d["trace_iters"]):
+        out = native_fit_x(d, it)
+        pose = np.concatenate([d["trace_" + k][ti] for k, _ in POSE_FIELDS], axis=1)
+        shape = np.concatenate([d["trace_betas"][ti], d["trace_expression"][ti]], axis=1)
+        for key, want in (("global_orient", d["trace_global_orient"][ti]), ("body_pose", pose), ("betas", shape), ("transl", d["trace_transl"][ti])):
+            err = np.abs(out[key].cpu().numpy() - want).max()
+            worst = max(worst, err)
+            assert err < PARAM_TOL, f"{case} iteration {int(it)}: {key} differs by {err}"
+        np.testing.assert_allclose(out["loss"].cpu().numpy(), d["iter_losses"][:, int(it) - 1], rtol=2e-4, err_msg=f"{case} it {int(it)}")
+    out = native_fit_x(d, d["num_iters"])
+    go, pose, shape, tr = pack(d, "out_")
+    for key, want in (("global_orient", go), ("body_pose", pose), ("betas", shape), ("transl", tr)):
+        assert np.abs(out[key].cpu().numpy() - want).max() < PARAM_TOL, (case, key)
+    j, v = H.native_model_x().lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"])
+    assert np.abs(j.cpu().numpy() - d["out_joints"]).max() < PARAM_TOL
+    assert np.abs(v[:, torch.as_tensor(d["sampled_vertex_ids"]).cuda()].cpu().numpy() - d["out_verts_sampled"]).max() < PARAM_TOL
+    if int(d["freeze_betas"]):
+        assert torch.equal(out["betas"][:, :10].cpu(), torch.tensor(d["init_betas"]))
+    print(f"smplx {case}: worst parameter deviation over the trace = {worst:.2e}")
+
+
+def test_smplx_fitter_api_returns_smplx_data():
+    """The reference-shaped entry: WorldSpaceFitter.fit_frame with SMPLXData in -> SMPLXData out, all ten fields fitted."""
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.models.smpl_data import SMPLXData
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+    d = H.load_smplx_case("all55_zero_init")
+    g = H.gmm_fixture()
+    c = H.body_consts_x()
+    model = BodyModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents, c.extra_vertex_ids)
+    assert model.model_type == "smplx" and model.num_betas == 10 and model.num_expression_coeffs == 10
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=int(d["num_iters"]), use_lbfgs=False,
+                              joints_category="GENERIC", pose_prior=prior)
+    fields = ("global_orient", "body_pose", "transl", "left_hand_pose", "right_hand_pose", "expression", "jaw_pose", "leye_pose",
+              "reye_pose", "betas")
+    init = SMPLXData(**{k: torch.tensor(d["init_" + k][:1]) for k in fields})
+    res = fitter.fit_frame(init, torch.tensor(d["j3d"][:1]), conf_3d=torch.tensor(d["conf"]), seq_ind=0,
+                           target_model_indices=torch.tensor(d["target_model_indices"]))
+    assert isinstance(res.params, SMPLXData)
+    for k in fields:
+        assert np.abs(getattr(res.params, k).cpu().numpy() - d["out_" + k][:1]).max() < PARAM_TOL, k
+    assert tuple(res.joints.shape) == (1, 127, 3) and tuple(res.vertices.shape) == (1, 10475, 3)
+    assert abs(float(res.loss) - float(d["out_loss"][0])) < 2e-4 * float(d["out_loss"][0])
+
+
+def test_smplx_1024_frames_are_independent_and_deterministic():
+    """BASELINE config 4 at full size: 1024 SMPL-X frames in one launch equal the same frames fitted in two halves, bit for
+    bit (frames never interact), twice (determinism); the joint error drops."""
+    from keypoints2body_amd import native, synthetic
+    B = 1024
+    p = synthetic.make_poses_x(B, seed=9)
+    m, pr = H.native_model_x(), H.native_prior()
+    pose = np.concatenate([getattr(p, k) for k, _ in POSE_FIELDS], axis=1)
+    shape = np.concatenate([p.betas, p.expression], axis=1)
+    j, _ = m.lbs(H.cuda(p.global_orient), H.cuda(pose), H.cuda(shape), H.cuda(p.transl), want_vertices=False)
+    j3d = j[:, :55].contiguous()
+    cfg = native.default_fit_config(); cfg.num_iters = 40; cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
+    z = lambda c: torch.zeros(B, c, device="cuda")
+    tr0 = (j3d[:, 0] - m.lbs(z(3), z(162), z(20), None, want_vertices=False)[0][:, 0]).contiguous()
+    run = lambda sl: native.fit_world(m, pr, cfg, list(range(55)), j3d[sl].contiguous(), None, z(3)[sl], z(162)[sl], z(20)[sl], tr0[sl].contiguous())
+    full, again = run(slice(0, B)), run(slice(0, B))
+    a, b = run(slice(0, 500)), run(slice(500, B))
+    for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+        assert torch.equal(full[k], again[k]), k
+        assert torch.equal(full[k], torch.cat([a[k], b[k]])), k
+    jf, _ = m.lbs(full["global_orient"], full["body_pose"], full["betas"], full["transl"], want_vertices=False)
+    err0 = (m.lbs(z(3), z(162), z(20), tr0, want_vertices=False)[0][:, :55] - j3d).norm(dim=-1).mean()
+    err1 = (jf[:, :55] - j3d).norm(dim=-1).mean()
+    assert err1 < 0.35 * err0, (float(err0), float(err1))

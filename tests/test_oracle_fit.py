@@ -103,3 +103,34 @@ def test_oracle_reproduces_reference_shape_pass():
     assert np.abs(betas.numpy() - d["out_betas"]).max() < 2e-5
     # (the joint term has weight 1 here against 25 |beta|^2 per frame, so the reference's pre-pass
     #  returns betas ~ 0 even for targets generated with a distinct shape: pinned as it behaves)
+
+
+SMPLX_CASES = ("all55_zero_init", "amass22_zero_init", "all55_followup_frozen")
+
+
+@pytest.mark.parametrize("case", SMPLX_CASES)
+def test_oracle_reproduces_reference_smplx_fit(case):
+    """SMPL-X goldens (oracle/gen_golden_smplx.py: the real reference fitter with SMPLXData, 55-joint tree, its prior
+    evaluated at [body_pose | 0 x 6]) against the oracle's SMPL-X restatement, at every recorded iteration."""
+    from oracle.fit_torch import SMPLX_FIELDS, fit_world_adam_smplx
+    d = H.load_smplx_case(case)
+    t = lambda k: torch.tensor(d[k])
+    idx = [int(i) for i in d["target_model_indices"]] if d["target_model_indices"].size else list(range(22))
+    params, loss, joints, verts, trace = fit_world_adam_smplx(
+        H.oracle_model_x(), H.oracle_prior(), {k: t("init_" + k) for k in SMPLX_FIELDS}, t("j3d"),
+        t("conf") if int(d["has_conf"]) else None, num_iters=int(d["num_iters"]), seq_ind=int(d["seq_ind"]), model_idx=idx,
+        freeze_betas=bool(int(d["freeze_betas"])), trace_iters=tuple(int(i) for i in d["trace_iters"]))
+    for ti, it in enumerate(d["trace_iters"]):
+        for k in SMPLX_FIELDS:
+            assert np.abs(trace[int(it)][k].numpy() - d["trace_" + k][ti]).max() < TOL, (case, int(it), k)
+    for k in SMPLX_FIELDS:
+        assert np.abs(params[k].numpy() - d["out_" + k]).max() < TOL, (case, k)
+    assert np.abs(joints.numpy() - d["out_joints"]).max() < TOL
+    assert np.abs(verts[:, torch.as_tensor(d["sampled_vertex_ids"])].numpy() - d["out_verts_sampled"]).max() < TOL
+    np.testing.assert_allclose(loss.numpy(), d["iter_losses"][:, -1], rtol=1e-5)
+    if case == "amass22_zero_init":          # no target on hands / face: their poses never move (the expression does: it is a
+        for k in ("left_hand_pose", "right_hand_pose", "jaw_pose", "leye_pose", "reye_pose"):   # shape coefficient of every joint)
+            assert np.array_equal(params[k].numpy(), d["init_" + k])
+    if int(d["freeze_betas"]):
+        assert np.array_equal(params["betas"].numpy(), d["init_betas"])
+        assert np.abs(params["expression"].numpy() - d["init_expression"]).max() > 1e-4    # the expression stays free

@@ -8,6 +8,6 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ff
 for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_lbs.hip -o /tmp/k2b_lbs_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libk2b_$name.so k2b_api.o k2b_fit.o /tmp/k2b_lbs_$name.o k2b_precompute.o k2b_metrics.o k2b_vertex.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libk2b_$name.so k2b_api.o k2b_fit.o k2b_fit_tree.o /tmp/k2b_lbs_$name.o k2b_precompute.o k2b_metrics.o k2b_vertex.o
   echo "built tools/libk2b_$name.so ($defs)"
 done
