@@ -81,7 +81,7 @@ struct k2b_model {
     } mesh, extra;
     // tables of the tree fit kernel (any J <= 64), lane order = DFS pre-order
     float *tt_dt = nullptr, *tt_dd = nullptr;
-    int* tt_tab = nullptr;
+    int *tt_tab = nullptr, *tt_anc = nullptr;
     std::vector<int> tt_lane_of;                             // lane of every joint
     int groups_a = 0;                                        // GA = ceil(J / 8)
     k2b::k2b_half* wsA2 = nullptr;                           // per-frame A operand of the tile kernel
@@ -344,7 +344,18 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                         m->h_j_dirs[(j * 3 + c) * NB + k] - (p >= 0 ? m->h_j_dirs[(p * 3 + c) * NB + k] : 0.f);
             }
         }
+        // ancestors 1, 2, 4, 8 levels up (pointer doubling); 63 = "none": a lane that is no joint and holds the identity
+        std::vector<int> tanc((size_t)64 * 4, 63);
+        if (J <= 63)
+            for (int l = 0; l < J; ++l) {
+                int aj = order[l];
+                for (int r = 0, dist = 0; r < 4; ++r) {
+                    for (; dist < (1 << r) && aj >= 0; ++dist) aj = parents[aj];
+                    tanc[l * 4 + r] = aj >= 0 ? lane_of[aj] : 63;
+                }
+            }
         m->tt_lane_of = lane_of;
+        HIP_TRY(upload(&m->tt_anc, tanc.data(), tanc.size()));
         HIP_TRY(upload(&m->tt_dt, tdt.data(), tdt.size()));
         HIP_TRY(upload(&m->tt_dd, tdd.data(), tdd.size()));
         HIP_TRY(upload(&m->tt_tab, tt.data(), tt.size()));
@@ -366,6 +377,7 @@ void k2b_model_destroy(k2b_model* m) {
     if (m->tt_dt) (void)hipFree(m->tt_dt);
     if (m->tt_dd) (void)hipFree(m->tt_dd);
     if (m->tt_tab) (void)hipFree(m->tt_tab);
+    if (m->tt_anc) (void)hipFree(m->tt_anc);
     for (k2b::k2b_half* p : hl) if (p) (void)hipFree(p);
     if (m->parents) (void)hipFree(m->parents);
     if (m->extra_ids) (void)hipFree(m->extra_ids);
@@ -556,7 +568,8 @@ int folded_prior(k2b_prior* p, int Dv, k2b_prior::Folded* out) {
     if (it != p->folded.end()) { *out = it->second; return K2B_OK; }
     const int M = p->M, D = p->D;
     constexpr int MG = k2b::kPriorMaxGauss;
-    std::vector<float> A((size_t)MG * 16 * 64 * 4, 0.f), h((size_t)MG * 64, 0.f), b((size_t)MG * 64, 0.f), mu((size_t)MG * 64, 0.f), cl(MG, 0.f);
+    std::vector<float> A((size_t)MG * 16 * 64 * 4, 0.f), h((size_t)MG * 64, 0.f), b((size_t)MG * 64, 0.f), mu((size_t)MG * 64, 0.f),
+        cl(MG, 3.0e38f);                                     // components beyond M: never the arg-min
     for (int m = 0; m < M; ++m) {
         auto P = [&](int i, int j) { return p->Ps[((size_t)m * D + i) * D + j]; };
         double c = 0.0;
@@ -644,8 +657,11 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
             last = {model, prior_dims};
         }
     }
-    a.dt = model->tt_dt; a.dd = model->tt_dd; a.tab = model->tt_tab;
-    a.num_joints = J; a.num_shape = NB; a.max_depth = maxd;
+    a.dt = model->tt_dt; a.dd = model->tt_dd; a.tab = model->tt_tab; a.anc = model->tt_anc;
+    a.num_joints = J; a.num_shape = NB;
+    a.num_rounds = 0;
+    while ((1 << a.num_rounds) < maxd + 1) ++a.num_rounds;
+    if (J > 63 || a.num_rounds > 4) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the tree kernel takes up to 63 joints and depth 15");
     a.pA = f.pA; a.ph = f.ph; a.pb = f.pb; a.pmu = f.pmu; a.pcl = f.pcl;
     a.num_gauss = prior->M; a.prior_dims = prior_dims;
     a.num_frames = B; a.num_targets = K;

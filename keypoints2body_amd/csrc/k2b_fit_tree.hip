@@ -22,6 +22,7 @@
 // Loss terms, Adam arithmetic and the "loss of the last iteration before its step" convention are those of
 // k2b_fit.hip (oracle: oracle/fit_torch.py; goldens: tests/golden/smplx_fit_*.npz).
 #include "k2b_internal.h"
+#include "k2b_lanes.h"
 
 namespace k2b {
 
@@ -33,17 +34,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 
-// inclusive prefix sum over the 64 lanes, in double (Hillis-Steele; six rounds)
-__device__ __forceinline__ double wave_scan(float v, int lane) {
-    double s = (double)v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(s, off, 64);
-        if (lane >= off) s += o;
-    }
-    return s;
-}
-__device__ __forceinline__ double shfl64(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double shfl64(double v, int src) { return bperm64(src << 2, v); }
 
 template <int NS>                        // capacity for shape coefficients (betas | expression): 16 or 32
 __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs a) {
@@ -56,20 +47,23 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int J = a.num_joints, NB = a.num_shape, M = a.num_gauss, Dv = a.prior_dims;
+    const int J = a.num_joints, NB = a.num_shape, Dv = a.prior_dims;
     const int fr_raw = blockIdx.x * TW + wave;
     const bool frame_ok = fr_raw < a.num_frames;
     const int fr = frame_ok ? fr_raw : a.num_frames - 1;           // idle waves shadow the last frame and write nothing
 
     // ---- prior image -> LDS (whole workgroup) ---------------------------------------------------------------------------
-    for (int i = threadIdx.x; i < M * 16 * 64; i += 64 * TW)
+    for (int i = threadIdx.x; i < TMG * 16 * 64; i += 64 * TW)
         reinterpret_cast<float4*>(sA)[i] = reinterpret_cast<const float4*>(a.pA)[i];
-    for (int i = threadIdx.x; i < M * 64; i += 64 * TW) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
+    for (int i = threadIdx.x; i < TMG * 64; i += 64 * TW) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
     __syncthreads();
 
     // ---- per-lane constants ---------------------------------------------------------------------------------------------
     const int* tb = a.tab + lane * 8;
-    const int joint = tb[0], plane = tb[1], ssize = tb[2], depth = tb[3];
+    const int joint = tb[0], ssize = tb[2];
+    int anc[4];                                  // byte address (lane x 4) of the ancestor 2^r levels up, or of lane 63
+#pragma unroll
+    for (int r = 0; r < 4; ++r) anc[r] = a.anc[lane * 4 + r] << 2;
     const int psrc = tb[4], pcomp = tb[5];       // prior layout: lane i takes theta[pcomp] of lane psrc (or -1)
     const int pd0 = tb[6];                       // tree layout: this joint's first prior dimension (or -1)
     const bool isJ = lane < J;
@@ -122,25 +116,26 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         // ---- rest offset from the parent: d = dt + dd . shape -------------------------------------------------------------
         float dx = dtx, dy = dty, dz = dtz;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            if (k < NB) {
-                const float sk = read_lane(sh, k);
-                dx = fmaf(dd[0][k], sk, dx); dy = fmaf(dd[1][k], sk, dy); dz = fmaf(dd[2][k], sk, dz);
-            }
+        for (int k = 0; k < NS; ++k) {               // (directions beyond NB are zero: no branch on the runtime count)
+            const float sk = read_lane(sh, k);
+            dx = fmaf(dd[0][k], sk, dx); dy = fmaf(dd[1][k], sk, dy); dz = fmaf(dd[2][k], sk, dz);
         }
         const Rodrigues rod = rodrigues_fwd({th[0], th[1], th[2]});
 
-        // ---- forward kinematics, level by level --------------------------------------------------------------------------------
+        // ---- forward kinematics by pointer doubling: after round r a lane holds its transform relative to the ancestor
+        // 2^(r+1) levels up (global once it runs out of ancestors).  Lanes without an ancestor at that distance fetch
+        // lane 63, which is no joint and holds the identity throughout: no select in the rounds.
         Mat3 Rg = rod.R;
         Vec3 pg = {dx, dy, dz};
-        for (int lev = 1; lev <= a.max_depth; ++lev) {
-            Mat3 pR;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) pR.m[i] = shfl(Rg.m[i], plane);
-            const Vec3 pp = {shfl(pg.x, plane), shfl(pg.y, plane), shfl(pg.z, plane)};
-            if (depth == lev) {
-                pg = mul(pR, Vec3{dx, dy, dz}) + pp;
-                Rg = mul(pR, rod.R);
+        for (int r = 0; r < 4; ++r) {
+            if (r < a.num_rounds) {
+                Mat3 pR;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) pR.m[i] = bperm(anc[r], Rg.m[i]);
+                const Vec3 pp = {bperm(anc[r], pg.x), bperm(anc[r], pg.y), bperm(anc[r], pg.z)};
+                pg = mul(pR, pg) + pp;
+                Rg = mul(pR, Rg);
             }
         }
 
@@ -164,7 +159,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         const int hi = lane + ssize - 1 < 63 ? lane + ssize - 1 : 63, lo = lane > 0 ? lane - 1 : 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const double pre = wave_scan(isJ ? v6[i] : 0.f, lane);
+            const double pre = wave_inclusive_scan(isJ ? v6[i] : 0.f, lane);
             const double up = shfl64(pre, hi), dn = shfl64(pre, lo);
             sub[i] = (float)(up - (lane > 0 ? dn : 0.0));
         }
@@ -190,12 +185,14 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         // shape coefficients through the rest offsets: g_k = sum_l gd_l . dd_l[:, k]  (+ shape prior on the betas)
         gsh = 0.f;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            if (k < NB) {
-                const float part = isJ ? gd.x * dd[0][k] + gd.y * dd[1][k] + gd.z * dd[2][k] : 0.f;
-                const float tot = wave_sum(part);
-                if (lane == k) gsh = tot;
-            }
+        for (int blk = 0; blk < NS / 16; ++blk) {        // 16 coefficients per butterfly: lane l ends with the total of k = (l >> 2) & 15
+            float part[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                part[k] = isJ ? gd.x * dd[0][16 * blk + k] + gd.y * dd[1][16 * blk + k] + gd.z * dd[2][16 * blk + k] : 0.f;
+            const float tot = butterfly16_sum(part, lane);
+            const float mine = shfl(tot, (lane & 15) << 2);          // coefficient 16 blk + (lane & 15) sits in lanes 4 k .. 4 k + 3
+            if ((lane >> 4) == blk) gsh = mine;
         }
         float lsh = 0.f;
         if (lane < a.num_betas_prior) { lsh = wsh * sh * sh; gsh += 2.f * wsh * sh; }
@@ -209,30 +206,31 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         float gv = 0.f, lv = 0.f;                // gradient and loss contributions in prior layout
         float lpr = 0.f;
         if (wpp > 0.f) {
-            float y[TMG];
+            float y[TMG];                            // (components beyond M: zero image, +inf constant - never the arg-min)
 #pragma unroll
-            for (int m = 0; m < TMG; ++m) y[m] = m < M ? sH[m * 64 + lane] : 0.f;
-#pragma unroll
+            for (int m = 0; m < TMG; ++m) y[m] = sH[m * 64 + lane];
+#pragma unroll 2     // (fully unrolled, the scheduler hoists all 128 LDS reads and spills 500 registers)
             for (int c = 0; c < 16; ++c) {
                 const float q0 = read_lane(thv, 4 * c), q1 = read_lane(thv, 4 * c + 1), q2 = read_lane(thv, 4 * c + 2),
                             q3 = read_lane(thv, 4 * c + 3);
 #pragma unroll
                 for (int m = 0; m < TMG; ++m) {
-                    if (m < M) {
-                        const floatx4 A4 = *reinterpret_cast<const floatx4*>(sA + ((m * 16 + c) * 64 + lane) * 4);
-                        y[m] = fmaf(A4[0], q0, fmaf(A4[1], q1, fmaf(A4[2], q2, fmaf(A4[3], q3, y[m]))));
-                    }
+                    const floatx4 A4 = *reinterpret_cast<const floatx4*>(sA + ((m * 16 + c) * 64 + lane) * 4);
+                    y[m] = fmaf(A4[0], q0, fmaf(A4[1], q1, fmaf(A4[2], q2, fmaf(A4[3], q3, y[m]))));
                 }
             }
             float best = 3.0e38f;
             int bm = 0;
+            float pcl[TMG];
+#pragma unroll
+            for (int m = 0; m < TMG; ++m) pcl[m] = a.pcl[m];
 #pragma unroll
             for (int m = 0; m < TMG; ++m) {
-                if (m < M) {
-                    const float dq = isP ? (thv - sMu[m * 64 + lane]) * (y[m] + sB[m * 64 + lane]) : 0.f;
-                    const float ell = 0.5f * wave_sum(dq) + a.pcl[m];
-                    if (ell < best) { best = ell; bm = m; }      // first minimum wins, as torch.min does
-                }
+                const float dq = isP ? (thv - sMu[m * 64 + lane]) * (y[m] + sB[m * 64 + lane]) : 0.f;
+                const float ell = 0.5f * wave_sum_fast(dq) + pcl[m];
+                const bool lt = ell < best;                      // first minimum wins, as torch.min does
+                best = lt ? ell : best;
+                bm = lt ? m : bm;
             }
             float yb = y[0];
 #pragma unroll
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             const float a0 = shfl(gv, s0i), a1 = shfl(gv, s0i + 1 < 64 ? s0i + 1 : 63), a2 = shfl(gv, s0i + 2 < 64 ? s0i + 2 : 63);
             if (pd0 >= 0) { gth[0] += a0; gth[1] += a1; gth[2] += a2; }
         }
-        loss_total = wave_sum(lj + lsh + lv) + lpr;
+        loss_total = wave_sum_fast(lj + lsh + lv) + lpr;
 
         // ---- Adam (torch.optim.Adam, single-tensor path; bias terms from the host table) ----------------------------------------------
         const float2 co = a.adam_coef[it];

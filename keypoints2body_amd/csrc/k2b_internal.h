@@ -71,7 +71,8 @@ struct FitTreeArgs {
     const float* dd;            // [64][3][32]  the same for the shape directions, zero padded
     const int* tab;             // [64][8]: joint, parent lane, subtree size, depth, prior source lane, prior source
                                 //          component, first prior dimension of this joint (-1: none), unused
-    int num_joints, num_shape, max_depth;
+    const int* anc;             // [64][4]: lane of the ancestor 1, 2, 4, 8 levels up, or 63 (a non-joint lane: identity)
+    int num_joints, num_shape, num_rounds;   // pointer-doubling rounds the targeted joints need: 2^rounds > their depth
     // prior (device): the mixture folded to its first prior_dims <= 64 dimensions (see k2b_fit_tree.hip)
     const float* pA;            // [M][16][64][4]   A_m[i][4 c + k] at ((m 16 + c) 64 + i) 4 + k
     const float *ph, *pb, *pmu; // [M][64]          h = b - A mu, b, mu
