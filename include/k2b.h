@@ -169,6 +169,30 @@ int k2b_fit_world(const k2b_model *model, const k2b_prior *prior, const k2b_fit_
                   float *loss_out, float *grad_out, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * k2b_fit_sequence — the reference's sequence mode as ONE launch.  Replaces the frame loop of
+ * `optimize_params_sequence` with `use_previous_frame_init=True` (api/sequence.py:214-281): frame 0 of
+ * a sequence is fitted from the given start with cfg->num_iters iterations and no preserve term
+ * (seq_ind == 0: world_space.py:159,211); every later frame starts from the previous frame's
+ * RESULT, preserves that result's body pose with cfg->pose_preserve_weight (world_space.py:159) and
+ * runs `followup_iters` iterations (world_space.py:214) with a fresh Adam state.  The chain of one
+ * sequence is serial (one cooperating wavefront pair walks it); num_sequences chains run side by side.
+ *
+ *   j3d  dev [S][T][K][3], conf dev [K] or [S][T][K] (conf_per_frame)
+ *   *_in dev [S][...]: start of frame 0 of every sequence
+ *   *_out dev [S][T][...], loss_out dev [S][T]: every frame's fitted parameters / last-iteration loss
+ * 24-joint models with a full-width mixture only (others: K2B_ERR_UNSUPPORTED - fit frame by frame);
+ * cfg->transl_prior_weight must be 0.
+ * ------------------------------------------------------------------------------- */
+int k2b_fit_sequence(const k2b_model *model, const k2b_prior *prior, const k2b_fit_config *cfg,
+                     int32_t num_sequences, int32_t frames_per_sequence, int32_t followup_iters,
+                     int32_t num_targets, const int32_t *model_joint_index,
+                     const float *j3d, const float *conf,
+                     const float *global_orient_in, const float *body_pose_in, const float *betas_in,
+                     const float *transl_in,
+                     float *global_orient_out, float *body_pose_out, float *betas_out, float *transl_out,
+                     float *loss_out, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * k2b_lbs — full SMPL forward.  Replaces `self.smpl(**kwargs)` (smplx `SMPL.forward`,
  * call sites world_space.py:34,192,278; engine.py:114) for a batch:
  *   joints_out dev [B][J+E][3], vertices_out dev [B][V][3] (NULL: joints only; the E

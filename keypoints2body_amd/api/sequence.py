@@ -4,8 +4,10 @@
 Two execution modes, both with the reference's per-frame semantics:
 
 * ``use_previous_frame_init=True`` (reference default): every frame starts from the previous
-  frame's result, an inherently sequential chain (``api/sequence.py:280-281``): one single-frame
-  launch per frame;
+  frame's result, an inherently sequential chain (``api/sequence.py:280-281``).  World mode, Adam branch,
+  24-joint model, kinematic targets: the WHOLE chain is one launch (``k2b_fit_sequence``: the frame loop runs
+  inside the kernel, parameters and optimiser state never leave registers) followed by one final forward over
+  all frames; any other configuration: one single-frame call per frame;
 * ``use_previous_frame_init=False``: every frame starts from the same initial parameters, so
   the frames are independent and are fitted in TWO launches: frame 0
   (``num_iters_first``, no preserve term) and frames 1..T-1 as one batch
@@ -114,6 +116,13 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
 
     results: list[BodyModelFitResult] = []
     T = xyz.shape[0]
+    est = engine.estimator
+    if (seq_cfg.use_previous_frame_init and T > 1 and frame_cfg.coordinate_mode == "world"
+            and hasattr(est.fitter, "chain_supported") and est.fitter.chain_supported(model_indices)):
+        if prev.transl is None:
+            prev = _with_root_aligned_transl(prev, xyz[0:1], model, frame_cfg, device)
+        out, joints, verts, loss = est.fit_chain(prev, xyz, conf, model_indices)
+        return _batched_results(est, out, joints, verts, loss, prev, T)
     if seq_cfg.use_previous_frame_init or T == 1:
         for idx in range(T):
             frame = xyz[idx: idx + 1]
@@ -131,20 +140,19 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
         prev = _with_root_aligned_transl(prev, xyz[0:1], model, frame_cfg, device)
     results.append(engine.fit_frame(init_params=prev, j3d=xyz[0:1], conf_3d=conf[0], seq_ind=0,
                                     target_model_indices=model_indices))
-    est = engine.estimator
     if not hasattr(est.fitter, "fit_batch"):          # camera-space fitter: one call per frame
         for idx in range(1, T):
             results.append(engine.fit_frame(init_params=prev, j3d=xyz[idx: idx + 1], conf_3d=conf[idx], seq_ind=idx,
                                             target_model_indices=model_indices))
         return results
     out, joints, verts, loss = _fit_independent_frames(est, prev, xyz[1:], conf[1:], model_indices, _process_group())
-    for i in range(T - 1):
-        sl = slice(i, i + 1)
-        results.append(BodyModelFitResult(
-            params=SMPLData(betas=out["betas"][sl], global_orient=out["global_orient"][sl],
-                            body_pose=out["body_pose"][sl], transl=out["transl"][sl]),
-            vertices=verts[sl], joints=joints[sl], loss=loss[i]))
-    return results
+    return results + _batched_results(est, out, joints, verts, loss, prev, T - 1)
+
+
+def _batched_results(est, out, joints, verts, loss, init, n) -> list[BodyModelFitResult]:
+    """Per-frame result objects (the data class the reference returns for the model / input type) of a batched fit."""
+    return [BodyModelFitResult(params=est.fitter.result_params(out, init, slice(i, i + 1)), vertices=verts[i: i + 1],
+                               joints=joints[i: i + 1], loss=loss[i]) for i in range(n)]
 
 
 def optimize_shape_sequence(joints_seq, *, body_model: ModelType = "smpl", joint_layout: Optional[str] = None,

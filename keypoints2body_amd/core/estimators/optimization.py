@@ -58,3 +58,8 @@ class OptimizationEstimator:
         """B independent frames in one launch (not part of the reference protocol)."""
         return self._fitter.fit_batch(init_params, j3d, conf_3d, seq_ind, target_model_indices,
                                       per_frame_conf=per_frame_conf, run_forward=run_forward, **self._weights())
+
+    def fit_chain(self, init_params, j3d, conf_3d, target_model_indices=None, run_forward=True):
+        """One sequence in warm-start mode as one launch (``WorldSpaceFitter.fit_chain``)."""
+        return self._fitter.fit_chain(init_params, j3d, conf_3d, target_model_indices, run_forward=run_forward,
+                                      **self._weights())

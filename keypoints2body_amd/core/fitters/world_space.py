@@ -159,15 +159,10 @@ class WorldSpaceFitter:
             raise ValueError(f"expected a (B,{cols}) tensor, got {tuple(t.shape)}")
         return t.contiguous()
 
-    def fit_batch(self, init_params: SMPLData, j3d, conf_3d=None, seq_ind: int = 0, target_model_indices=None,
-                  joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = False,
-                  per_frame_conf: bool = False, want_vertices: bool = True, run_forward: bool = True):
-        """Fit B independent frames in one launch.
-
-        Returns ``(params: dict of (B,.) tensors, joints, vertices, per_frame_loss)``; with
-        ``run_forward=False`` the final forward is left to the caller (``final_forward``) and joints / vertices
-        are ``None`` - the sharded sequence path gathers the parameters first.
-        """
+    def _prepare(self, init_params, j3d, conf_3d, target_model_indices, per_frame_conf, num_init=None):
+        """Argument handling shared by ``fit_batch`` and ``fit_chain``: device tensors in kernel layout, the joint
+        gather of world_space.py:194-201 and the confidence rules of world_space.py:163-164.  ``num_init``: expected
+        rows of ``init_params`` (default: one per frame of ``j3d``)."""
         if init_params.transl is None:
             raise ValueError("init_params.transl must be provided")
         j3d = torch.as_tensor(j3d, dtype=torch.float32)
@@ -187,7 +182,7 @@ class WorldSpaceFitter:
             bp = self._dev(init_params.body_pose, 3 * (J - 1))
             be = self._dev(init_params.betas, self.smpl.num_betas)
         tr = self._dev(init_params.transl, 3)
-        if not (go.shape[0] == bp.shape[0] == be.shape[0] == tr.shape[0] == B):
+        if not (go.shape[0] == bp.shape[0] == be.shape[0] == tr.shape[0] == (B if num_init is None else num_init)):
             raise ValueError("init_params and j3d disagree on the number of frames")
 
         # joint gather (world_space.py:194-201): model joint per target, and the target rows
@@ -214,6 +209,20 @@ class WorldSpaceFitter:
         else:
             conf = None
 
+        return go, bp, be, tr, model_idx, tgt, conf
+
+    def fit_batch(self, init_params: SMPLData, j3d, conf_3d=None, seq_ind: int = 0, target_model_indices=None,
+                  joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = False,
+                  per_frame_conf: bool = False, want_vertices: bool = True, run_forward: bool = True):
+        """Fit B independent frames in one launch.
+
+        Returns ``(params: dict of (B,.) tensors, joints, vertices, per_frame_loss)``; with
+        ``run_forward=False`` the final forward is left to the caller (``final_forward``) and joints / vertices
+        are ``None`` - the sharded sequence path gathers the parameters first.
+        """
+        go, bp, be, tr, model_idx, tgt, conf = self._prepare(init_params, j3d, conf_3d, target_model_indices, per_frame_conf)
+        J = self.smpl.num_joints
+        smplx = self.smpl.model_type == "smplx"
         cfg = self._config(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
                            per_frame_conf and conf is not None and conf.dim() == 2)
         if smplx:
@@ -227,6 +236,39 @@ class WorldSpaceFitter:
             out = self._fit_lbfgs(cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas)
         else:
             out = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, go, bp, be, tr)
+        if not run_forward:
+            return out, None, None, out["loss"]
+        joints, verts = self.final_forward(out, want_vertices=want_vertices)
+        return out, joints, verts, out["loss"]
+
+    def chain_supported(self, target_model_indices=None) -> bool:
+        """Whether ``fit_chain`` can run this fitter's sequence mode in one launch: Adam branch, 24-joint model,
+        kinematic targets only (otherwise the caller fits frame by frame)."""
+        if self.use_lbfgs or self.smpl.num_joints != 24:
+            return False
+        idx = self.smpl_index if target_model_indices is None else torch.as_tensor(target_model_indices).reshape(-1).tolist()
+        return idx is not None and all(int(i) < self.smpl.num_joints for i in idx)
+
+    def fit_chain(self, init_params: SMPLData, j3d, conf_3d=None, target_model_indices=None,
+                  joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = False,
+                  want_vertices: bool = True, run_forward: bool = True):
+        """The reference's sequence mode (``api/sequence.py:214-281`` with ``use_previous_frame_init=True``) for ONE
+        sequence of T frames in one launch (``k2b_fit_sequence``): frame 0 as ``seq_ind == 0`` from ``init_params``
+        (one row), every later frame from its predecessor's result with the preserve term and
+        ``num_iters_followup`` iterations.  ``conf_3d``: (K,) or per frame (T, K) as the sequence API passes it.
+        Returns ``(params: dict of (T,.) tensors, joints, vertices, per_frame_loss)`` like ``fit_batch``."""
+        if not self.chain_supported(target_model_indices):
+            raise NotImplementedError("fit_chain: Adam branch with a 24-joint model and kinematic targets only")
+        per_frame = conf_3d is not None and torch.as_tensor(conf_3d).dim() == 2
+        go, bp, be, tr, model_idx, tgt, conf = self._prepare(init_params, j3d, conf_3d, target_model_indices, per_frame,
+                                                             num_init=1)
+        cfg = self._config(0, joint_loss_weight, pose_preserve_weight, freeze_betas, per_frame)
+        cfg.pose_preserve_weight = float(pose_preserve_weight)      # frames >= 1 (frame 0 has no preserve term)
+        T = tgt.shape[0]
+        out = native.fit_sequence(self.smpl.native, self.pose_prior.native, cfg, int(self.num_iters_followup), model_idx,
+                                  tgt.unsqueeze(0), None if conf is None else (conf.unsqueeze(0) if per_frame else conf),
+                                  go, bp, be, tr)
+        out = {k: v.reshape((T,) + tuple(v.shape[2:])) for k, v in out.items()}
         if not run_forward:
             return out, None, None, out["loss"]
         joints, verts = self.final_forward(out, want_vertices=want_vertices)
@@ -330,13 +372,20 @@ class WorldSpaceFitter:
         out, joints, verts, loss = self.fit_batch(
             init_params, j3d, conf_3d, seq_ind, target_model_indices, joint_loss_weight, pose_preserve_weight,
             freeze_betas, per_frame_conf=False)
+        return BodyModelFitResult(params=self.result_params(out, init_params), vertices=verts, joints=joints, loss=loss.sum())
+
+    def result_params(self, out, init_params, rows: Optional[slice] = None):
+        """Fitted parameters as the data class the reference returns for this model / input type; `rows` selects
+        frames of a batched result (hand / face fields a 24-joint fit does not touch are carried from `init_params`)."""
+        if rows is not None:
+            out = {k: v[rows] for k, v in out.items() if k != "loss"}
         if self.smpl.model_type == "smplx":
             u = self.smpl.unpack(out["body_pose"], out["betas"])
             fitted = SMPLXData(betas=u["betas"], global_orient=out["global_orient"], body_pose=u["body_pose"],
                                transl=out["transl"], left_hand_pose=u["left_hand_pose"], right_hand_pose=u["right_hand_pose"],
                                expression=u["expression"], jaw_pose=u["jaw_pose"], leye_pose=u["leye_pose"],
                                reye_pose=u["reye_pose"])
-            return BodyModelFitResult(params=fitted, vertices=verts, joints=joints, loss=loss.sum())
+            return fitted
         fields = dict(betas=out["betas"], global_orient=out["global_orient"], body_pose=out["body_pose"],
                       transl=out["transl"])
         if isinstance(init_params, SMPLXData):
@@ -347,7 +396,7 @@ class WorldSpaceFitter:
             fitted = SMPLHData(**fields, **{k: _detached(getattr(init_params, k)) for k in keep})
         else:
             fitted = SMPLData(**fields)
-        return BodyModelFitResult(params=fitted, vertices=verts, joints=joints, loss=loss.sum())
+        return fitted
 
 
 def _detached(x):

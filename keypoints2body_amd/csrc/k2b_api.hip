@@ -682,17 +682,25 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
 }
 }  // namespace
 
-int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
-                  const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
-                  const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
-                  const float* tr_prior, float* go_out,
-                  float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream) {
+namespace {
+int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
+                   const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
+                   const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
+                   const float* tr_prior, float* go_out,
+                   float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream,
+                   int chain_len, int chain_iters) {
     k2b_model* model = const_cast<k2b_model*>(model_c);
     if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
     const int pose_dims_all = 3 * (model->J - 1);
     const int prior_dims = cfg->prior_pose_dims > 0 ? cfg->prior_pose_dims : (prior->D < pose_dims_all ? prior->D : pose_dims_all);
     const bool small_tree = model->fit_ok && prior->D == pose_dims_all && prior_dims == pose_dims_all &&
                             (cfg->num_betas_prior == 0 || cfg->num_betas_prior == model->NB);
+    if (!small_tree && chain_len > 1)
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_sequence: warm-start chains are built for the 24-joint kernel only (fit frame by frame)");
+    if (chain_len > 1 && (chain_iters < 1 || chain_iters > (1 << 20)))
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_sequence: followup_iters=%d", chain_iters);
+    if (chain_len > 1 && (preserve || tr_prior || grad_out || cfg->transl_prior_weight != 0.0f))
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_sequence: no explicit preserve pose, translation prior or gradient output in a chain");
     if (!small_tree)
         return fit_tree(model, const_cast<k2b_prior*>(prior), cfg, prior_dims, B, K, model_joint_index, j3d, conf, go_in, bp_in, be_in, tr_in,
                         preserve, tr_prior, go_out, bp_out, be_out, tr_out, loss_out, grad_out, stream);
@@ -725,7 +733,11 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     }
 
     float2* coef = nullptr;
-    if (const int rc = adam_table(model, cfg, (hipStream_t)stream, &coef); rc != K2B_OK) return rc;
+    {   // a chain's follow-up frames restart the optimiser: one table long enough for both counts, each reads its prefix
+        k2b_fit_config tc = *cfg;
+        if (chain_len > 1 && chain_iters > tc.num_iters) tc.num_iters = chain_iters;
+        if (const int rc = adam_table(model, &tc, (hipStream_t)stream, &coef); rc != K2B_OK) return rc;
+    }
 
     a.dt = model->dt; a.dd = model->dd; a.lane_tab = model->tree;
     // global transforms are only needed down to the deepest targeted joint: 2^rounds > its depth
@@ -762,9 +774,39 @@ int k2b_fit_world(const k2b_model* model_c, const k2b_prior* prior, const k2b_fi
     if (cfg->debug_launch_shape < 0 || cfg->debug_launch_shape > 3)
         return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: debug_launch_shape=%d must be 0..3", cfg->debug_launch_shape);
     a.force_shape = cfg->debug_launch_shape;
+    a.chain_len = chain_len > 1 ? chain_len : 1;
+    a.chain_iters = chain_iters;
     a.num_cus = device_cus();
     HIP_TRY(k2b::launch_fit_world(a, (hipStream_t)stream));
     return K2B_OK;
+}
+}  // namespace
+
+int k2b_fit_world(const k2b_model* model, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
+                  const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
+                  const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
+                  const float* tr_prior, float* go_out,
+                  float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream) {
+    return fit_world_impl(model, prior, cfg, B, K, model_joint_index, j3d, conf, go_in, bp_in, be_in, tr_in, preserve, tr_prior,
+                          go_out, bp_out, be_out, tr_out, loss_out, grad_out, stream, 1, 0);
+}
+
+int k2b_fit_sequence(const k2b_model* model, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t num_sequences,
+                     int32_t frames_per_sequence, int32_t followup_iters, int32_t K, const int32_t* model_joint_index,
+                     const float* j3d, const float* conf, const float* go_in, const float* bp_in, const float* be_in,
+                     const float* tr_in, float* go_out, float* bp_out, float* be_out, float* tr_out, float* loss_out,
+                     void* stream) {
+    if (frames_per_sequence < 1) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_sequence: frames_per_sequence=%d", frames_per_sequence);
+    if ((int64_t)num_sequences * frames_per_sequence > (int64_t)1 << 30)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_sequence: %d x %d frames", num_sequences, frames_per_sequence);
+    if (frames_per_sequence == 1) {           // a chain of one: the first-frame fit (no preserve term)
+        k2b_fit_config c1 = *cfg;
+        c1.pose_preserve_weight = 0.0f;
+        return fit_world_impl(model, prior, &c1, num_sequences, K, model_joint_index, j3d, conf, go_in, bp_in, be_in, tr_in, nullptr,
+                              nullptr, go_out, bp_out, be_out, tr_out, loss_out, nullptr, stream, 1, 0);
+    }
+    return fit_world_impl(model, prior, cfg, num_sequences, K, model_joint_index, j3d, conf, go_in, bp_in, be_in, tr_in, nullptr, nullptr,
+                          go_out, bp_out, be_out, tr_out, loss_out, nullptr, stream, frames_per_sequence, followup_iters);
 }
 
 namespace {

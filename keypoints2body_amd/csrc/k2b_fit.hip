@@ -316,10 +316,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     Vec3 tgt = {0.f, 0.f, 0.f};
     float wconf = 0.f;  // w_j^2 c^2
     if (tk >= 0) {
-        const int ft = PAIR ? (hb ? f[FW - 1] : f[0]) : f[0];
-        const float* y = a.j3d + ((size_t)ft * a.num_targets + tk) * 3;
+        const size_t ft = (size_t)(PAIR ? (hb ? f[FW - 1] : f[0]) : f[0]) * (a.chain_len > 1 ? a.chain_len : 1);
+        const float* y = a.j3d + (ft * a.num_targets + tk) * 3;
         tgt = {y[0], y[1], y[2]};
-        const float c = a.conf ? a.conf[(a.conf_per_frame ? (size_t)ft * a.num_targets : 0) + tk] : 1.0f;
+        const float c = a.conf ? a.conf[(a.conf_per_frame ? ft * a.num_targets : 0) + tk] : 1.0f;
         wconf = (a.joint_w * a.joint_w) * (c * c);
     }
 
@@ -347,11 +347,15 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const float wpp2 = a.pose_prior_w * a.pose_prior_w;
     const float wa2 = a.angle_w * a.angle_w;
     const float ws2 = a.shape_w * a.shape_w;
-    const float wpr2 = a.preserve_w * a.preserve_w;
+    // warm-start chain (a.chain_len > 1, split shape only): every slot is a SEQUENCE; step 0 is its first frame (no
+    // preserve term, a.num_iters iterations), the later steps start from the previous step's result, preserve it and
+    // run a.chain_iters iterations with a fresh optimiser state (reference api/sequence.py:214-281, world_space.py:159,211,214)
+    const bool chain = !PAIR && a.chain_len > 1;
+    float wpr2 = chain ? 0.f : a.preserve_w * a.preserve_w;
     const float wt2 = a.transl_prior_w * a.transl_prior_w;
     // set-B coefficients of the priors: gradient c_y y + 2 c_q (x - ref), loss share c_q (x - ref)^2
     const float cyB = bodyB ? wpp2 : 0.f;
-    const float cqB = bodyB ? wpr2 : (betaB ? ws2 : (translB ? wt2 : 0.f));
+    float cqB = bodyB ? wpr2 : (betaB ? ws2 : (translB ? wt2 : 0.f));
     float refB[FW];
 #pragma unroll
     for (int h = 0; h < FW; ++h) refB[h] = bodyB ? pr1[h] : (translB ? tp1[h] : 0.f);
@@ -690,10 +694,21 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // component registers and the row waves no tree registers.
     if (SPLIT && wave >= 4) {
         // tree waves: kinematics, joint loss, analytic backward
-        for (int it = 0; it < a.num_iters; ++it) {
-            __syncthreads();
-            if (do_tree) tree_pass(it == a.num_iters - 1);
-            __syncthreads();
+        const int steps = PAIR ? 1 : a.chain_len;
+        for (int step = 0; step < steps; ++step) {
+            const int nit = step == 0 ? a.num_iters : a.chain_iters;
+            if (!PAIR && step > 0 && tk >= 0) {           // targets of this step's frame (sequence s, frame row s chain_len + step)
+                const size_t ft = (size_t)f[0] * a.chain_len + step;
+                const float* y = a.j3d + (ft * a.num_targets + tk) * 3;
+                tgt = {y[0], y[1], y[2]};
+                const float c = a.conf ? a.conf[(a.conf_per_frame ? ft * a.num_targets : 0) + tk] : 1.0f;
+                wconf = (a.joint_w * a.joint_w) * (c * c);
+            }
+            for (int it = 0; it < nit; ++it) {
+                __syncthreads();
+                if (do_tree) tree_pass(it == nit - 1);
+                __syncthreads();
+            }
         }
         return;
     }
@@ -711,8 +726,25 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 plo[(((wave + 4) * 4 + t) * 2 + ks) * 64 + lane] = pb_l[t][ks];
                 if (PAIR) plo[((wave * 4 + t) * 2 + ks) * 64 + lane] = pa_l[t][ks];   // two frames of optimiser state: both
             }
-        for (int it = 0; it < a.num_iters; ++it) {
-            const bool last = it == a.num_iters - 1;
+        auto out_ptr_c = [&](size_t fr, int p) -> float* {
+            if (p < 3) return a.go_out + fr * 3 + p;
+            if (p < 3 + D) return a.bp_out + fr * D + (p - 3);
+            if (p < 3 + D + NB) return a.be_out + fr * NB + (p - 3 - D);
+            return a.tr_out + fr * 3 + (p - 3 - D - NB);
+        };
+        int git = 0;                 // iterations over all chain steps (the row waves' meeting counter runs on)
+        const int steps = PAIR ? 1 : a.chain_len;
+        for (int step = 0; step < steps; ++step) {
+            const int nit = step == 0 ? a.num_iters : a.chain_iters;
+            if (!PAIR && step > 0) { // (chain: FW == 1) start from the previous result, preserve it, fresh Adam state
+                wpr2 = a.preserve_w * a.preserve_w;
+                cqB = bodyB ? wpr2 : cqB;
+                pr0[0] = x0[0];
+                if (bodyB) { pr1[0] = x1[0]; refB[0] = x1[0]; }
+                m0[0] = v0[0] = m1[0] = v1[0] = 0.f;
+            }
+        for (int it = 0; it < nit; ++it, ++git) {
+            const bool last = it == nit - 1;
             if (do_row) publish();
             __syncthreads();
             floatx4 ya[4], yb[4];
@@ -729,13 +761,21 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 // arg-min and the priors' gradient are done while the tree waves still work, and only
                 // "add the joint gradient, Adam, publish" is left on the iteration's critical path
                 if (lane == 0) __hip_atomic_fetch_add(row_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int target = 4 * (it + 1);
+                const int target = 4 * (git + 1);
                 while (__hip_atomic_load(row_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
             if (do_row) row_prior(last);
             __syncthreads();
             if (do_row) row_finish(it, last);
         }
+            if (!PAIR && chain && do_row && f_valid[0]) {     // this step's frame: row s chain_len + step
+                const size_t fr = (size_t)f[0] * a.chain_len + step;
+                *out_ptr_c(fr, pA) = x0[0];
+                if (actB) *out_ptr_c(fr, pB) = x1[0];
+                if (lane == 0 && a.loss_out) a.loss_out[fr] = loss_total[0];
+            }
+        }
+        if (chain) return;
     } else {
         // paired: every wave carries component `wave` and the row and tree roles of its two slots
         half8 pa_h[4][2], pa_l[4][2];
@@ -804,6 +844,18 @@ static FitArgs frame_range(const FitArgs& a, int f0, int n) {
 
 hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     if (a_in.num_frames <= 0) return hipSuccess;
+    if (a_in.chain_len > 1) {
+        // warm-start chains: num_frames sequences, one split-shape slot each (the chain is serial, so the shape that
+        // gives one frame the most hardware is the one to use), up to four sequences per workgroup
+        FitArgs a = a_in;
+        int fpw = (a.num_frames + a.num_cus - 1) / a.num_cus;
+        fpw = fpw < 1 ? 1 : (fpw > 4 ? 4 : fpw);
+        a.frames_per_wg = fpw;
+        const dim3 grid((a.num_frames + fpw - 1) / fpw), block(MAXW * 64);
+        if (a.num_betas <= 10) hipLaunchKernelGGL((k2b_fit_world_kernel<10, MODE_SPLIT>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k2b_fit_world_kernel<16, MODE_SPLIT>), grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
     // More frames than one full-width launch of the densest shape holds (16 per CU): such a launch runs in rounds of
     // num_cus workgroups, each as long as a full one however few workgroups it has (10 000 frames: 625 workgroups =
     // 2.4 rounds, paid as 3).  Launch the whole rounds first and the remainder on its own, in the shape that suits
@@ -816,6 +868,7 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
         return launch_fit_world(frame_range(a_in, head, a_in.num_frames - head), stream);
     }
     FitArgs a = a_in;
+    a.chain_len = 1;
     // frame slots per workgroup: enough to cover the batch with one workgroup per CU.  Up to 4: split
     // (SIMDs would idle, so every frame gets two cooperating waves); up to 8: one wave per frame;
     // beyond: two frames per wave.

@@ -26,7 +26,7 @@ K2B_ERR_NO_DEVICE = -4
 EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
     "k2b_model_joint_basis", "k2b_model_reserve", "k2b_debug_lbs_kernel", "k2b_debug_read_dump", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
-    "k2b_fit_world", "k2b_lbs", "k2b_vertex_term", "k2b_adam_step", "k2b_angular_error_deg",
+    "k2b_fit_world", "k2b_fit_sequence", "k2b_lbs", "k2b_vertex_term", "k2b_adam_step", "k2b_angular_error_deg",
 )
 
 
@@ -102,6 +102,8 @@ def load_library():
         raise RuntimeError("libk2b.so was built with a different k2b_fit_config layout than native.FitConfigC")
     lib.k2b_fit_world.restype = C.c_int
     lib.k2b_fit_world.argtypes = [vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 14 + [vp]
+    lib.k2b_fit_sequence.restype = C.c_int
+    lib.k2b_fit_sequence.argtypes = [vp, vp, C.POINTER(FitConfigC)] + [C.c_int32] * 4 + [ip] + [fp] * 11 + [vp]
     lib.k2b_lbs.restype = C.c_int
     lib.k2b_lbs.argtypes = [vp, C.c_int32] + [fp] * 6 + [vp]
     lib.k2b_vertex_term.restype = C.c_int
@@ -310,6 +312,41 @@ def fit_world(model: NativeModel, prior: NativePrior, cfg: FitConfigC, model_joi
             C.c_void_p(out["betas"].data_ptr()), C.c_void_p(out["transl"].data_ptr()),
             C.c_void_p(out["loss"].data_ptr()),
             C.c_void_p(out["grad"].data_ptr()) if want_grad else None, stream), "k2b_fit_world")
+    return out
+
+
+def fit_sequence(model: NativeModel, prior: NativePrior, cfg: FitConfigC, followup_iters: int,
+                 model_joint_index: Sequence[int], j3d: torch.Tensor, conf: Optional[torch.Tensor],
+                 global_orient: torch.Tensor, body_pose: torch.Tensor, betas: torch.Tensor, transl: torch.Tensor):
+    """Warm-start chains in one launch (``k2b_fit_sequence``): ``j3d`` (S, T, K, 3), start parameters (S, ...) of every
+    sequence's first frame; returns (S, T, ...) tensors.  ``cfg.num_iters`` iterations for frame 0, ``followup_iters``
+    for the others, ``cfg.pose_preserve_weight`` on frames >= 1."""
+    dev = model.device
+    S, T, K = j3d.shape[0], j3d.shape[1], j3d.shape[2]
+    D = 3 * (model.num_joints - 1)
+    idx = _host_i32(np.asarray(list(model_joint_index)))
+    if idx.shape != (K,):
+        raise ValueError(f"model_joint_index has {idx.shape[0]} entries for {K} targets")
+    conf_p = None
+    if conf is not None:
+        conf_p = _dev(conf, "conf", dev, (S, T, K) if cfg.conf_per_frame else (K,))
+    out = {
+        "global_orient": torch.empty((S, T, 3), dtype=torch.float32, device=dev),
+        "body_pose": torch.empty((S, T, D), dtype=torch.float32, device=dev),
+        "betas": torch.empty((S, T, model.num_betas), dtype=torch.float32, device=dev),
+        "transl": torch.empty((S, T, 3), dtype=torch.float32, device=dev),
+        "loss": torch.empty((S, T), dtype=torch.float32, device=dev),
+    }
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _check(load_library().k2b_fit_sequence(
+            model.handle, prior.handle, C.byref(cfg), S, T, int(followup_iters), K, _np_ptr(idx),
+            _dev(j3d, "j3d", dev, (S, T, K, 3)), conf_p,
+            _dev(global_orient, "global_orient", dev, (S, 3)), _dev(body_pose, "body_pose", dev, (S, D)),
+            _dev(betas, "betas", dev, (S, model.num_betas)), _dev(transl, "transl", dev, (S, 3)),
+            C.c_void_p(out["global_orient"].data_ptr()), C.c_void_p(out["body_pose"].data_ptr()),
+            C.c_void_p(out["betas"].data_ptr()), C.c_void_p(out["transl"].data_ptr()),
+            C.c_void_p(out["loss"].data_ptr()), stream), "k2b_fit_sequence")
     return out
 
 

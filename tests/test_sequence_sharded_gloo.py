@@ -33,6 +33,12 @@ class _Fitter:
                            transl=out["transl"])
         return o.joints, o.vertices
 
+    def result_params(self, out, init, rows=None):
+        from keypoints2body_amd.models.smpl_data import SMPLData
+        sl = slice(None) if rows is None else rows
+        return SMPLData(betas=out["betas"][sl], global_orient=out["global_orient"][sl], body_pose=out["body_pose"][sl],
+                        transl=out["transl"][sl])
+
 
 class _Estimator:
     def __init__(self, model, prior, cfg):
