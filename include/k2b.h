@@ -148,7 +148,11 @@ uint32_t k2b_fit_config_size(void);
  *
  *   model_joint_index [K] HOST int32: model joint fitted to target k (the reference's
  *       smpl_index / target_model_indices, world_space.py:194-201); values must be
- *       distinct and < J (vertex-selected joints >= J: K2B_ERR_UNSUPPORTED).
+ *       distinct.  Indices >= J name smplx's vertex-selected "extra" joints (24-joint models, at
+ *       most 32 of them, at least one kinematic joint beside them): the call then queues TWO
+ *       launches per iteration on the stream - the fused kernel in evaluate-only mode and the
+ *       vertex-term kernel with its Adam tail - with no host work in between; conf may be per
+ *       frame there too.
  *   j3d  dev [B][K][3]   target joints (already gathered with corr_index)
  *   conf dev [K] or [B][K] (see conf_per_frame); NULL = ones
  *   *_in dev: initial global_orient [B][3], body_pose [B][3(J-1)], betas [B][NB], transl [B][3]
@@ -210,19 +214,16 @@ void k2b_debug_lbs_kernel(int32_t which);
 int k2b_debug_read_dump(const k2b_model *model, void *host, int64_t nbytes);
 
 /* ---------------------------------------------------------------------------------
- * Vertex-selected joints in the loss (slow path).  `target_model_indices` of the reference
+ * Vertex-selected joints in the loss, stand-alone pieces.  `target_model_indices` of the reference
  * (world_space.py:198-201) may name smplx's "extra" joints, which are single mesh vertices
- * (index J + e, e < E).  The fused kernel fits kinematic joints only; for the others the
- * host runs the Adam loop itself with three launches per iteration: k2b_fit_world in
- * evaluate-only mode (num_iters = 1, step_size = 0, grad_out) for the kinematic targets and
- * the priors, k2b_vertex_term for the vertex targets, k2b_adam_step for the update.
+ * (index J + e, e < E).  k2b_fit_world handles them itself (see model_joint_index above); these
+ * two entry points expose the pieces it is made of, for optimisers that run on the host (the
+ * L-BFGS branch may call k2b_fit_world in evaluate-only mode instead) and for the parity tests.
  *
  * k2b_vertex_term: loss [B] and gradient [B][3 + 3(J-1) + NB + 3] (layout of grad_out above)
  *   of  joint_loss_weight^2 conf_e^2 sum_xyz gmof(vertex_e + transl - target_e)  over the E_sel
  *   selected extra joints; extra_index HOST int32 [E_sel] in [0, E); targets dev [B][E_sel][3];
  *   conf dev [E_sel] or NULL.  At most 32 selected joints per call.
- *   The selection is kept in a per-model device buffer (re-uploaded, after a stream sync, when it changes):
- *   calls on one model that use DIFFERENT selections must not be in flight on different streams at once.
  * k2b_adam_step: torch.optim.Adam single-tensor update of n floats for step t = 1, 2, ...
  *   (bias corrections formed in double like the fused kernel's table); m, v are the caller's
  *   state buffers (zero before the first step).

@@ -22,8 +22,8 @@ outer algorithm of both stages, as the reference does; every closure evaluation 
 launch of the same kernel with the stage's configuration (loss and analytic gradient, no autograd
 graph).  L-BFGS couples the parameters it is given, so that mode fits one frame at a time.
 
-Vertex-selected joints among ``target_model_indices`` (model index >= 24) take the world fitter's slow path
-in both stages (host-driven Adam loop, ``world_space.adam_with_vertex_joints``).
+Vertex-selected joints among ``target_model_indices`` (model index >= 24) are handled inside ``k2b_fit_world`` in
+both stages (two launches per iteration queued by the one call: fused kernel evaluate-only + vertex term with Adam tail).
 
 Like the reference (whose broadcasts only hold for one frame per call) ``fit_frame`` treats every
 frame independently; unlike it, any number of frames may be passed at once.
@@ -39,7 +39,6 @@ from ...models.body_model import BodyModel, as_body_model
 from ...models.smpl_data import BodyModelFitResult, SMPLData
 from ...prior import MaxMixturePrior
 from ..constants import JOINT_MAP, TORSO_JOINTS, category_indices
-from .world_space import adam_with_vertex_joints, evaluate_with_vertex_joints, split_targets
 
 _TORSO_IDX = [JOINT_MAP[name] for name in TORSO_JOINTS]     # same indices in the AMASS numbering
 _SQUARED_ERROR_SIGMA = 1.0e8                                # gmof(e, sigma) -> e^2 in fp32
@@ -131,16 +130,10 @@ class CameraSpaceFitter:
         cam_t0 = cam_t0.detach().contiguous()
 
         def fit(cfg, idx, tgt, cf, p):
+            # (vertex-selected joints among the targets are handled inside k2b_fit_world)
             cur = (p["global_orient"], p["body_pose"], p["betas"], p["transl"])
-            if not any(i >= J for i in idx):
-                return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt, cf, *cur,
-                                        transl_prior_target=cam_t0)
-            # vertex-selected joints among the targets: the slow path of the world fitter (host-driven Adam loop)
-            if int(cfg.num_iters) == 1 and float(cfg.step_size) == 0.0:
-                r = evaluate_with_vertex_joints(self.smpl, self.pose_prior, cfg, split_targets(self.smpl, idx, tgt, cf), *cur,
-                                                want_grad=False, transl_prior_target=cam_t0)
-                return dict(p, loss=r["loss"])
-            return adam_with_vertex_joints(self.smpl, self.pose_prior, cfg, idx, tgt, cf, *cur, transl_prior_target=cam_t0)
+            return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt, cf, *cur,
+                                    transl_prior_target=cam_t0)
 
         cfg1, cfg2, fit_betas = self.stage_configs(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas, depth_w)
         start = dict(global_orient=go, body_pose=bp, betas=be, transl=cam_t0)
@@ -183,20 +176,14 @@ class CameraSpaceFitter:
                 cols = {"global_orient": slice(0, 3), "body_pose": slice(3, 3 + D), "betas": slice(3 + D, 3 + D + NB),
                         "transl": slice(3 + D + NB, 3 + D + NB + 3)}
 
-                vertex_joints = any(i >= self.smpl.num_joints for i in idx)
-
                 def closure():
                     with torch.no_grad():
                         cur = (p["global_orient"].detach().contiguous(), p["body_pose"].detach().contiguous(),
                                p["betas"].detach().contiguous(), p["transl"].detach().contiguous())
                         kw = dict(preserve_pose=preserve[sl].contiguous(), want_grad=True,
                                   transl_prior_target=cam_t0[sl].contiguous())
-                        if vertex_joints:
-                            r = evaluate_with_vertex_joints(self.smpl, self.pose_prior, cfg,
-                                                            split_targets(self.smpl, idx, tgt[sl].contiguous(), cfv), *cur, **kw)
-                        else:
-                            r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt[sl].contiguous(), cfv,
-                                                 *cur, **kw)
+                        r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt[sl].contiguous(), cfv,
+                                             *cur, **kw)
                     for k in opt_keys:
                         p[k].grad = r["grad"][:, cols[k]].clone()
                     return r["loss"].sum()

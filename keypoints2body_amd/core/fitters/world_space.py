@@ -24,11 +24,11 @@ Differences, all deliberate and documented in DESIGN.md:
   pose / shape vector.  The reference hands SMPL-X's 63-D body pose to its 69-D mixture, which raises (SURVEY.md N3);
   here the mixture is evaluated at ``[body_pose | 0 x 6]``, and hands are full axis-angle poses (``use_pca=False``).
   With a 24-joint model, hand / face fields of ``SMPLHData`` / ``SMPLXData`` inputs are carried through unchanged;
-* vertex-selected joints (model joint index >= 24: smplx's "extra" joints, single mesh vertices) take a slow
-  path: the fused kernel fits kinematic joints only, so the Adam loop then runs on the host with three
-  launches per iteration (``k2b_fit_world`` evaluate-only for the kinematic targets and the priors,
-  ``k2b_vertex_term`` for the vertex targets, ``k2b_adam_step``); roughly ten times the fused path's time
-  (the LBFGS branch adds the vertex term to its closure the same way);
+* vertex-selected joints (model joint index >= 24: smplx's "extra" joints, single mesh vertices): the fused
+  kernel fits kinematic joints only, so ``k2b_fit_world`` then queues two launches per iteration (its kernel in
+  evaluate-only mode for the kinematic targets and the priors, the vertex-term kernel with an Adam tail for the
+  vertex targets and the step) - still one C call per fit, no host work between the launches, per-frame
+  confidences allowed (the LBFGS branch gets loss and gradient of both terms from one evaluate-only call);
 * ``fit_batch`` fits B independent frames in one launch with optional per-frame
   confidences; ``fit_frame`` keeps the reference's behaviour of using row 0 of a 2-D
   confidence tensor (``world_space.py:163-164``).
@@ -57,71 +57,6 @@ def guess_init_transl_from_root(smpl_model, pose_aa, betas, j3d_world_frame, joi
     out = model(global_orient=pose_aa[:, :3], body_pose=pose_aa[:, 3:], betas=betas, return_verts=False)
     target = torch.as_tensor(j3d_world_frame, dtype=torch.float32).to(model.device)
     return (target[:, root_target, :] - out.joints[:, root_model, :]).detach()
-
-
-def split_targets(smpl, model_idx, tgt, conf):
-    """Kinematic targets (fused kernel) and vertex-selected ones (``k2b_vertex_term``) of a target list."""
-    J = smpl.num_joints
-    if conf is not None and conf.dim() == 2:
-        raise NotImplementedError("per-frame confidences with vertex-selected joints")
-    kin = [k for k, i in enumerate(model_idx) if i < J]
-    vtx = [k for k, i in enumerate(model_idx) if i >= J]
-    if not kin:
-        raise NotImplementedError("at least one kinematic joint (model index < %d) must be among the targets" % J)
-    num_extra = smpl.native.num_extra
-    if any(model_idx[k] - J >= num_extra for k in vtx):
-        raise ValueError(f"target_model_indices must be < {J + num_extra}")
-    pick = lambda rows: None if conf is None else conf[rows].contiguous()
-    return ([model_idx[k] for k in kin], tgt[:, kin].contiguous(), pick(kin),
-            [model_idx[k] - J for k in vtx], tgt[:, vtx].contiguous(), pick(vtx))
-
-
-def evaluate_with_vertex_joints(smpl, prior, cfg, split, go, bp, be, tr, preserve_pose=None, want_grad=True,
-                                transl_prior_target=None):
-    """Loss (and gradient) at the given parameters when some targets are vertex-selected joints: the kinematic
-    targets and every prior from an evaluate-only launch of the fused kernel (``cfg`` must have ``num_iters = 1``,
-    ``step_size = 0``), the vertex targets from ``k2b_vertex_term``.  ``split`` is ``split_targets``' result."""
-    kin_idx, tgt_k, conf_k, vtx_idx, tgt_v, conf_v = split
-    ev = native.fit_world(smpl.native, prior.native, cfg, kin_idx, tgt_k, conf_k, go, bp, be, tr,
-                          preserve_pose=preserve_pose, want_grad=want_grad, transl_prior_target=transl_prior_target)
-    loss_v, grad_v = native.vertex_term(smpl.native, vtx_idx, tgt_v, conf_v, float(cfg.sigma), float(cfg.joint_loss_weight),
-                                        go, bp, be, tr)
-    out = {"loss": ev["loss"] + loss_v}
-    if want_grad:
-        out["grad"] = ev["grad"] + grad_v
-    return out
-
-
-def adam_with_vertex_joints(smpl, prior, cfg, model_idx, tgt, conf, go, bp, be, tr, transl_prior_target=None):
-    """The Adam loop driven from the host, for target lists with vertex-selected joints.  Per iteration: loss and
-    gradient from ``evaluate_with_vertex_joints`` (two launches), then one ``k2b_adam_step`` over the packed
-    parameters (the same arithmetic as the fused kernel's update; parameters outside ``cfg.optimize_mask`` get no
-    gradient).  Returns the same dict as ``native.fit_world``; ``loss`` is the loss of the last iteration before
-    its step (``world_space.py:256``).  ``cfg`` is left in its evaluate-only state."""
-    split = split_targets(smpl, model_idx, tgt, conf)
-    num_iters, lr = int(cfg.num_iters), float(cfg.step_size)
-    cfg.num_iters, cfg.step_size = 1, 0.0                     # evaluate-only launches of the fused kernel
-    B, D, NB = go.shape[0], bp.shape[1], be.shape[1]
-    cols = (slice(0, 3), slice(3, 3 + D), slice(3 + D, 3 + D + NB), slice(3 + D + NB, 3 + D + NB + 3))
-    params = torch.cat([go, bp, be, tr], dim=1).contiguous()
-    m, v = torch.zeros_like(params), torch.zeros_like(params)
-    preserve = bp.clone()
-    mask = int(cfg.optimize_mask) & (~4 if cfg.freeze_betas else ~0)
-    loss = None
-    for step in range(1, num_iters + 1):
-        p = [params[:, c].contiguous() for c in cols]
-        ev = evaluate_with_vertex_joints(smpl, prior, cfg, split, *p, preserve_pose=preserve,
-                                         transl_prior_target=transl_prior_target)
-        grad = ev["grad"]
-        for bit, c in zip((1, 2, 4, 8), cols):                # parameters outside the optimiser get no gradient
-            if not (mask & bit):
-                grad[:, c] = 0.0
-        loss = ev["loss"]
-        native.adam_step(params, grad.contiguous(), m, v, step, lr, float(cfg.adam_beta1), float(cfg.adam_beta2),
-                         float(cfg.adam_eps))
-    out = {k: params[:, c].contiguous() for k, c in zip(("global_orient", "body_pose", "betas", "transl"), cols)}
-    out["loss"] = loss if loss is not None else torch.zeros(B, device=params.device)
-    return out
 
 
 class WorldSpaceFitter:
@@ -230,9 +165,7 @@ class WorldSpaceFitter:
                 raise NotImplementedError("use_lbfgs=True with a 55-joint (SMPL-X) model: only the Adam branch is built for it")
             cfg.prior_pose_dims = 3 * self.smpl.NUM_BODY_JOINTS       # 63: what the mixture, bending and preserve terms see
             cfg.num_betas_prior = self.smpl.num_betas                 # 10: shape prior / freeze_betas leave the expression alone
-        if any(i >= J for i in model_idx) and not self.use_lbfgs:
-            out = self._fit_with_vertex_joints(cfg, model_idx, tgt, conf, go, bp, be, tr)
-        elif self.use_lbfgs:
+        if self.use_lbfgs:
             out = self._fit_lbfgs(cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas)
         else:
             out = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, go, bp, be, tr)
@@ -298,14 +231,6 @@ class WorldSpaceFitter:
         return self.smpl.native.lbs(out["global_orient"], out["body_pose"], out["betas"], out["transl"],
                                     want_vertices=want_vertices)
 
-    def _split_targets(self, model_idx, tgt, conf):
-        return split_targets(self.smpl, model_idx, tgt, conf)
-
-    def _fit_with_vertex_joints(self, cfg, model_idx, tgt, conf, go, bp, be, tr):
-        """Adam branch with vertex-selected joints among the targets (``world_space.py:198-201`` with indices
-        >= 24): see ``adam_with_vertex_joints``."""
-        return adam_with_vertex_joints(self.smpl, self.pose_prior, cfg, model_idx, tgt, conf, go, bp, be, tr)
-
     def _fit_lbfgs(self, cfg, model_idx, tgt, conf, go, bp, be, tr, freeze_betas):
         """LBFGS branch (world_space.py:231-247): ``torch.optim.LBFGS(params, max_iter=num_iters,
         lr=step_size, line_search_fn="strong_wolfe").step(closure)`` per frame, with the closure's
@@ -316,9 +241,6 @@ class WorldSpaceFitter:
         cfg.num_iters, cfg.step_size = 1, 0.0          # evaluate-only launches
         B, D = go.shape[0], bp.shape[1]
         NB = be.shape[1]
-        vtx_idx = []
-        if any(i >= self.smpl.num_joints for i in model_idx):      # vertex-selected joints: their term comes from k2b_vertex_term
-            model_idx, tgt, conf, vtx_idx, tgt_v, conf_v = self._split_targets(model_idx, tgt, conf)
         preserve = bp.clone()                          # world_space.py:159
         outs = {k: [] for k in ("global_orient", "body_pose", "betas", "transl", "loss")}
         for f in range(B):
@@ -336,15 +258,8 @@ class WorldSpaceFitter:
                 with torch.no_grad():
                     cur = (p[0].detach().contiguous(), p[1].detach().contiguous(), beta.detach().contiguous(),
                            p[2].detach().contiguous())
-                    r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt[sl].contiguous(),
-                                         cf, *cur, preserve_pose=pres, want_grad=want_grad)
-                    if vtx_idx:
-                        loss_v, grad_v = native.vertex_term(self.smpl.native, vtx_idx, tgt_v[sl].contiguous(), conf_v,
-                                                            float(cfg.sigma), float(cfg.joint_loss_weight), *cur)
-                        r["loss"] = r["loss"] + loss_v
-                        if want_grad:
-                            r["grad"] = r["grad"] + grad_v
-                    return r
+                    return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt[sl].contiguous(),
+                                            cf, *cur, preserve_pose=pres, want_grad=want_grad)
 
             def closure():
                 r = evaluate(True)

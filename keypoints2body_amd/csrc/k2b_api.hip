@@ -70,8 +70,6 @@ struct k2b_model {
     std::string fit_why;
     float *dt = nullptr, *dd = nullptr;
     int* tree = nullptr;
-    int* sel_ws = nullptr;                                   // device copy of the selected extra-joint indices (vertex term)
-    std::vector<int> sel_host;                               // ... and what it currently holds
     std::vector<int> depth;                                  // depth of every joint (root 0)
     // LBS B operands (f16 hi/lo, MFMA fragment order) for the whole mesh and for the E extra-joint vertices
     struct VertexSet {
@@ -382,7 +380,6 @@ void k2b_model_destroy(k2b_model* m) {
     if (m->parents) (void)hipFree(m->parents);
     if (m->extra_ids) (void)hipFree(m->extra_ids);
     if (m->tree) (void)hipFree(m->tree);
-    if (m->sel_ws) (void)hipFree(m->sel_ws);
     for (auto& kv : m->adam_tables) (void)hipFree(kv.second.dev);
     delete m;
 }
@@ -683,6 +680,73 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
 }  // namespace
 
 namespace {
+// Adam fit with vertex-selected joints among the targets (world_space.py:198-201 with indices >= J).  The fused kernel
+// fits kinematic joints only, so every iteration is two launches queued back to back: the fused kernel in evaluate-only
+// mode (kinematic targets + every prior -> loss, gradient) and the vertex-term kernel with its Adam tail (vertex targets,
+// sum of the gradients, the optimiser step in place).  `a` is the fused launch fully set up for the caller's buffers.
+int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, k2b::FitArgs a, const std::vector<int>& vsel,
+                            const std::vector<int>& vcol, hipStream_t stream) {
+    const int B = a.num_frames, NB = model->NB, D = 3 * (model->J - 1), P = 3 + D + NB + 3;
+    const int iters = cfg->num_iters;
+    float2 *coef = nullptr, *coef_eval = nullptr;
+    if (const int rc = adam_table(model, cfg, stream, &coef); rc != K2B_OK) return rc;
+    {
+        k2b_fit_config ec = *cfg;
+        ec.num_iters = 1;
+        ec.step_size = 0.0;
+        if (const int rc = adam_table(model, &ec, stream, &coef_eval); rc != K2B_OK) return rc;
+    }
+    // stream-ordered scratch: gradient and loss of the evaluate launch, Adam state, copies of the preserve pose and the
+    // translation prior's centre (their defaults are the INITIAL parameters, which the in-place steps overwrite)
+    const size_t n_g = (size_t)B * P, n_all = 3 * n_g + B + (size_t)B * D + (size_t)B * 3;
+    float* ws = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&ws, n_all * sizeof(float), stream));
+    float *gbuf = ws, *mbuf = ws + n_g, *vbuf = ws + 2 * n_g, *lbuf = ws + 3 * n_g, *pres = lbuf + B, *trp = pres + (size_t)B * D;
+    auto cleanup = [&](int rc) { (void)hipFreeAsync(ws, stream); return rc; };
+#define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_world: HIP call failed in the vertex-joint path")); } } while (0)
+    K2B_TRY_WS(hipMemsetAsync(mbuf, 0, 2 * n_g * sizeof(float), stream));
+    K2B_TRY_WS(hipMemcpyAsync(pres, a.preserve ? a.preserve : a.bp_in, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    K2B_TRY_WS(hipMemcpyAsync(trp, a.tr_prior, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    const struct { const float* src; float* dst; size_t n; } cp[] = {
+        {a.go_in, a.go_out, (size_t)B * 3}, {a.bp_in, a.bp_out, (size_t)B * D}, {a.be_in, a.be_out, (size_t)B * NB}, {a.tr_in, a.tr_out, (size_t)B * 3}};
+    for (const auto& c : cp)
+        if (c.src != c.dst) K2B_TRY_WS(hipMemcpyAsync(c.dst, c.src, c.n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    float* user_grad = a.grad_out;
+    float* user_loss = a.loss_out;
+    a.go_in = a.go_out; a.bp_in = a.bp_out; a.be_in = a.be_out; a.tr_in = a.tr_out;
+    a.preserve = pres; a.tr_prior = trp;
+    a.adam_coef = coef_eval; a.num_iters = 1;
+    a.loss_out = lbuf; a.grad_out = gbuf;
+
+    k2b::VertexTermArgs v{};
+    v.v_template = model->v_template; v.shapedirs = model->shapedirs; v.posedirs = model->posedirs; v.lbs_weights = model->lbs_weights;
+    v.j_template = model->j_template; v.j_dirs = model->j_dirs; v.parents = model->parents; v.extra_ids = model->extra_ids;
+    v.num_vertices = model->V; v.num_betas = NB;
+    v.num_frames = B; v.num_sel = (int)vsel.size();
+    for (size_t e = 0; e < vsel.size(); ++e) { v.sel[e] = vsel[e]; v.sel_k[e] = vcol[e]; }
+    v.num_targets = a.num_targets; v.targets = a.j3d; v.conf = a.conf; v.conf_per_frame = a.conf_per_frame;
+    v.sigma = a.sigma; v.joint_w = a.joint_w;
+    v.go = a.go_out; v.bp = a.bp_out; v.be = a.be_out; v.tr = a.tr_out;
+    v.go_w = a.go_out; v.bp_w = a.bp_out; v.be_w = a.be_out; v.tr_w = a.tr_out;
+    float* loss_sink = user_loss ? user_loss : lbuf;
+    v.loss_in = lbuf; v.grad_in = gbuf;
+    v.adam_m = mbuf; v.adam_v = vbuf;
+    v.one_minus_beta1 = a.one_minus_beta1; v.beta2 = a.beta2; v.one_minus_beta2 = a.one_minus_beta2; v.eps = a.eps;
+    v.opt_mask = a.opt_mask;
+    for (int it = 0; it < iters; ++it) {
+        K2B_TRY_WS(k2b::launch_fit_world(a, stream));
+        v.adam_coef = coef + it;
+        const bool last = it == iters - 1;
+        v.loss_out = last ? loss_sink : lbuf;        // (lbuf: read and written by the same lane)
+        v.grad_out = last ? user_grad : nullptr;
+        K2B_TRY_WS(k2b::launch_vertex_term(v, stream));
+    }
+#undef K2B_TRY_WS
+    return cleanup(K2B_OK);
+}
+}  // namespace
+
+namespace {
 int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
                    const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
                    const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
@@ -716,15 +780,26 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
 
     k2b::FitArgs a{};
     int lane_target[k2b::kFitJoints];
+    std::vector<int> vsel, vcol;             // vertex-selected joints: index into the model's extra joints, target column
+    int num_kinematic = 0;
     for (int j = 0; j < k2b::kFitJoints; ++j) lane_target[j] = -1;
     for (int k = 0; k < K; ++k) {
         const int j = model_joint_index[k];
         if (j < 0 || j >= model->J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index[%d]=%d out of range", k, j);
-        if (j >= model->J)
-            return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: model_joint_index[%d]=%d is a vertex-selected joint; the fused kernel fits kinematic joints only", k, j);
+        if (j >= model->J) {                 // vertex-selected joint: its term comes from k2b_vertex_term_kernel
+            if ((int)vsel.size() >= 32) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: more than 32 vertex-selected joints among the targets");
+            vsel.push_back(j - model->J);
+            vcol.push_back(k);
+            continue;
+        }
         if (lane_target[j] >= 0) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: joint %d is targeted twice", j);
         lane_target[j] = k;
+        ++num_kinematic;
     }
+    if (!vsel.empty() && num_kinematic == 0)
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: at least one kinematic joint (model index < %d) must be among the targets", model->J);
+    if (!vsel.empty() && chain_len > 1)
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_sequence: vertex-selected joints are not built into the chain (fit frame by frame)");
     for (int i = 0; i < 4; ++i) {
         const int ai = cfg->angle_prior_index[i];
         if (ai < 0 || ai >= 64) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: angle_prior_index[%d]=%d must be in [0,64)", i, ai);
@@ -743,7 +818,8 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     // global transforms are only needed down to the deepest targeted joint: 2^rounds > its depth
     {
         int maxd = 0;
-        for (int k = 0; k < K; ++k) maxd = model->depth[model_joint_index[k]] > maxd ? model->depth[model_joint_index[k]] : maxd;
+        for (int k = 0; k < K; ++k)
+            if (model_joint_index[k] < model->J) maxd = model->depth[model_joint_index[k]] > maxd ? model->depth[model_joint_index[k]] : maxd;
         int rounds = 0;
         while ((1 << rounds) < maxd + 1) ++rounds;
         a.num_rounds = rounds;
@@ -777,6 +853,7 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;
     a.num_cus = device_cus();
+    if (!vsel.empty()) return fit_world_vertex_joints(model, cfg, a, vsel, vcol, (hipStream_t)stream);
     HIP_TRY(k2b::launch_fit_world(a, (hipStream_t)stream));
     return K2B_OK;
 }
@@ -910,22 +987,13 @@ int k2b_vertex_term(const k2b_model* model_c, int32_t B, int32_t E_sel, const in
         if (extra_index[e] < 0 || extra_index[e] >= m->E)
             return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: extra_index[%d]=%d outside [0,%d)", e, extra_index[e], m->E);
     hipStream_t stream = (hipStream_t)stream_v;
-    {
-        // the selection is uploaded only when it changes (an Adam loop calls this once per iteration with the same one)
-        std::lock_guard<std::mutex> lk(m->mu);
-        if (!m->sel_ws) HIP_TRY(hipMalloc((void**)&m->sel_ws, 32 * sizeof(int)));
-        const std::vector<int> want(extra_index, extra_index + E_sel);
-        if (want != m->sel_host) {
-            HIP_TRY(hipStreamSynchronize(stream));                  // earlier launches may still read the old selection
-            HIP_TRY(hipMemcpy(m->sel_ws, want.data(), (size_t)E_sel * sizeof(int), hipMemcpyHostToDevice));
-            m->sel_host = want;
-        }
-    }
     k2b::VertexTermArgs a{};
     a.v_template = m->v_template; a.shapedirs = m->shapedirs; a.posedirs = m->posedirs; a.lbs_weights = m->lbs_weights;
     a.j_template = m->j_template; a.j_dirs = m->j_dirs; a.parents = m->parents; a.extra_ids = m->extra_ids;
     a.num_vertices = m->V; a.num_betas = m->NB;
-    a.num_frames = B; a.num_sel = E_sel; a.sel = m->sel_ws; a.targets = targets; a.conf = conf;
+    a.num_frames = B; a.num_sel = E_sel; a.targets = targets; a.conf = conf;
+    for (int e = 0; e < E_sel; ++e) { a.sel[e] = extra_index[e]; a.sel_k[e] = e; }
+    a.num_targets = E_sel;
     a.sigma = sigma; a.joint_w = joint_loss_weight;
     a.go = go; a.bp = bp; a.be = be; a.tr = tr; a.loss_out = loss_out; a.grad_out = grad_out;
     HIP_TRY(k2b::launch_vertex_term(a, stream));

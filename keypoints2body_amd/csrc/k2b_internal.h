@@ -182,12 +182,23 @@ struct VertexTermArgs {
     int num_vertices, num_betas;
     // call
     int num_frames, num_sel;
-    const int* sel;             // dev [num_sel]: index into extra_ids of every fitted vertex joint
-    const float* targets;       // dev [B][num_sel][3]
-    const float* conf;          // dev [num_sel] or null
+    int sel[32];                // index into extra_ids of every fitted vertex joint
+    int sel_k[32];              // its column in targets / conf
+    int num_targets;            // columns of targets / conf
+    const float* targets;       // dev [B][num_targets][3]
+    const float* conf;          // dev [num_targets] or [B][num_targets] (conf_per_frame) or null
+    int conf_per_frame;
     float sigma, joint_w;
     const float *go, *bp, *be, *tr;
-    float *loss_out, *grad_out; // dev [B], [B][3 + 69 + NB + 3]
+    float *loss_out, *grad_out; // dev [B], [B][3 + 69 + NB + 3] (grad_out may be null with the Adam tail)
+    // Adam tail (grad_in != null): the launch adds its loss / gradient to those of the evaluate-only launch of the fused
+    // kernel (loss_in, grad_in), applies the optimiser's membership mask and makes the frame's Adam step in place
+    const float *loss_in, *grad_in;
+    float *go_w, *bp_w, *be_w, *tr_w;   // the parameters again, writable (same buffers as go, bp, be, tr)
+    float *adam_m, *adam_v;             // dev [B][P]
+    const float2* adam_coef;            // this step's {lr / (1 - b1^t), sqrt(1 - b2^t)}
+    float one_minus_beta1, beta2, one_minus_beta2, eps;
+    int opt_mask;
 };
 hipError_t launch_vertex_term(const VertexTermArgs& a, hipStream_t stream);
 hipError_t launch_adam(float* x, const float* g, float* m, float* v, long long n, float lr_over_bc1, float sqrt_bc2,

@@ -4,10 +4,11 @@
 // The fused fit kernel (k2b_fit.hip) fits kinematic joints only: its loss never touches a vertex.  smplx
 // appends "extra" joints that are single mesh vertices (nose, eyes, ears, toes, heels, finger tips:
 // `vertex_joint_selector`), and the reference lets a caller fit them through `target_model_indices`
-// (core/fitters/world_space.py:198-201).  This file is the slow path for that case: per Adam iteration the host
-// launches (1) the fused kernel in evaluate-only mode for the kinematic targets and all priors, (2)
-// `k2b_vertex_term_kernel` for the vertex targets and (3) `k2b_adam_kernel`; see
-// keypoints2body_amd/core/fitters/world_space.py::_fit_with_vertex_joints.
+// (core/fitters/world_space.py:198-201).  This file is the path for that case: k2b_fit_world then queues, per Adam
+// iteration, (1) the fused kernel in evaluate-only mode for the kinematic targets and all priors and (2)
+// `k2b_vertex_term_kernel` with its Adam tail: vertex term, sum of both gradients, the frame's optimiser step
+// (k2b_api.hip::fit_world_vertex_joints; no host work between the launches).  Without the tail the kernel is the
+// stand-alone term behind k2b_vertex_term (L-BFGS closures, tests).
 //
 // Vertex term, one 64-lane workgroup per frame (a handful of vertices: written for clarity, not speed).
 // For a selected vertex with rest position, shape / pose blend rows and skinning weights (t, S, Pd, w):
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(64) void k2b_vertex_term_kernel(const VertexTermArg
     __shared__ float svp[VE][3], sg[VE][3], sgvp[VE][3];
     __shared__ float sF[VJ][3], sM[VJ][3];
     __shared__ float sGX[9 * (VJ - 1) + 1];
+    __shared__ float sGrad[3 + 3 * (VJ - 1) + kMaxBetas + 3];
     __shared__ int spar[VJ];
 
     const int f = blockIdx.x;
@@ -119,9 +121,10 @@ __global__ __launch_bounds__(64) void k2b_vertex_term_kernel(const VertexTermArg
             x.x += w * q.x; x.y += w * q.y; x.z += w * q.z;
         }
         const float tx = a.tr[(size_t)f * 3], ty = a.tr[(size_t)f * 3 + 1], tz = a.tr[(size_t)f * 3 + 2];
-        const float* y = a.targets + ((size_t)f * E + lane) * 3;
+        const int kcol = a.sel_k[lane];
+        const float* y = a.targets + ((size_t)f * a.num_targets + kcol) * 3;
         const float ex = x.x + tx - y[0], ey = x.y + ty - y[1], ez = x.z + tz - y[2];
-        const float cf = a.conf ? a.conf[lane] : 1.0f;
+        const float cf = a.conf ? a.conf[(a.conf_per_frame ? (size_t)f * a.num_targets : 0) + kcol] : 1.0f;
         const float wc = (a.joint_w * a.joint_w) * (cf * cf);
         const float s2 = a.sigma * a.sigma;
         const float x2 = ex * ex, y2 = ey * ey, z2 = ez * ez;
@@ -231,19 +234,42 @@ __global__ __launch_bounds__(64) void k2b_vertex_term_kernel(const VertexTermArg
 
     // ---- outputs ---------------------------------------------------------------------------------------------
     const int P = 3 + D + NB + 3;
-    float* go = a.grad_out + (size_t)f * P;
     if (isJ) {
-        float* dst = lane == 0 ? go : go + 3 + 3 * (lane - 1);
+        float* dst = lane == 0 ? sGrad : sGrad + 3 + 3 * (lane - 1);
         dst[0] = gth.x; dst[1] = gth.y; dst[2] = gth.z;
     }
 #pragma unroll
     for (int k = 0; k < kMaxBetas; ++k) {
         const float s = wave_sum(gbeta_part[k] + gbeta_v[k]);
-        if (lane == 0 && k < NB) go[3 + D + k] = s;
+        if (lane == 0 && k < NB) sGrad[3 + D + k] = s;
     }
     if (lane == 0) {
-        go[3 + D + NB] = gtx; go[3 + D + NB + 1] = gty; go[3 + D + NB + 2] = gtz;
-        a.loss_out[f] = loss;
+        sGrad[3 + D + NB] = gtx; sGrad[3 + D + NB + 1] = gty; sGrad[3 + D + NB + 2] = gtz;
+        a.loss_out[f] = loss + (a.loss_in ? a.loss_in[f] : 0.f);
+    }
+    __syncthreads();
+    if (!a.grad_in) {
+        for (int p = lane; p < P; p += 64) a.grad_out[(size_t)f * P + p] = sGrad[p];
+        return;
+    }
+    // Adam tail: total gradient (parameters outside the optimiser get none), torch.optim.Adam's single-tensor step
+    const float2 co = *a.adam_coef;
+    const float inv_bc2 = fast_rcp(co.y);
+    for (int p = lane; p < P; p += 64) {
+        const int group = p < 3 ? 0 : (p < 3 + D ? 1 : (p < 3 + D + NB ? 2 : 3));
+        const bool opt = (a.opt_mask >> group) & 1;
+        const float g = opt ? a.grad_in[(size_t)f * P + p] + sGrad[p] : 0.f;
+        if (a.grad_out) a.grad_out[(size_t)f * P + p] = g;
+        float* x = group == 0 ? a.go_w + (size_t)f * 3 + p
+                 : (group == 1 ? a.bp_w + (size_t)f * D + (p - 3)
+                 : (group == 2 ? a.be_w + (size_t)f * NB + (p - 3 - D) : a.tr_w + (size_t)f * 3 + (p - 3 - D - NB)));
+        const size_t i = (size_t)f * P + p;
+        const float mi = a.adam_m[i] + a.one_minus_beta1 * (g - a.adam_m[i]);
+        const float vi = a.adam_v[i] * a.beta2 + a.one_minus_beta2 * g * g;
+        const float denom = fast_sqrt(vi) * inv_bc2 + a.eps;
+        a.adam_m[i] = mi;
+        a.adam_v[i] = vi;
+        *x = *x - co.x * (mi * fast_rcp(denom));
     }
 }
 

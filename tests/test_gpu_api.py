@@ -159,9 +159,9 @@ def test_camera_space_fitter_matches_reference_golden(assets, case):
 
 def test_vertex_selected_joints_match_reference_golden(assets):
     """GENERIC targets that include smplx's vertex-selected joints (model indices 24, 25, 30, 37, 44 beside the 22
-    kinematic ones): the reference's fit differentiates through blend shapes and LBS of those vertices.  Here the
-    slow path of ``WorldSpaceFitter`` (evaluate-only fused kernel + ``k2b_vertex_term`` + ``k2b_adam_step`` per
-    iteration) must reproduce the reference's parameters at every recorded iteration, every iteration's loss and
+    kinematic ones): the reference's fit differentiates through blend shapes and LBS of those vertices.  Here
+    ``k2b_fit_world`` (per iteration: the fused kernel evaluate-only + the vertex-term kernel with its Adam tail, queued
+    by the one call) must reproduce the reference's parameters at every recorded iteration, every iteration's loss and
     the final joints, at the same 1e-4 as the fused path."""
     from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
     model, prior = assets
@@ -196,9 +196,37 @@ def test_vertex_selected_joints_match_reference_golden(assets):
     assert err(joints_l, out_l["transl"]) < 1.5 * err(joints, out["transl"]) + 1e-3
 
 
+def test_vertex_selected_joints_take_per_frame_confidences(assets):
+    """Per-frame confidences with vertex-selected joints among the targets: a batch with a (B, K) confidence tensor
+    must give, row by row, the bits of single-frame fits with that row's (K,) confidences."""
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    model, prior = assets
+    d = dict(np.load(H.GOLDEN / "world_fit_generic_vertex_joints.npz"))
+    idx = torch.tensor(d["target_model_indices"])
+    t = lambda k: torch.tensor(d[k])
+    B, K = d["j3d"].shape[0], d["j3d"].shape[1]
+    conf = torch.tensor(np.random.default_rng(0).uniform(0.5, 1.5, (B, K)).astype(np.float32))
+    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=12, use_lbfgs=False, joints_category="GENERIC", pose_prior=prior)
+    init = k2b.SMPLData(betas=t("init_betas"), global_orient=t("init_global_orient"), body_pose=t("init_body_pose"),
+                        transl=t("init_transl"))
+    out, _, _, loss = fitter.fit_batch(init, t("j3d"), conf_3d=conf, seq_ind=1, target_model_indices=idx, per_frame_conf=True,
+                                       run_forward=False)
+    for f in range(B):
+        sl = slice(f, f + 1)
+        one = k2b.SMPLData(betas=t("init_betas")[sl], global_orient=t("init_global_orient")[sl], body_pose=t("init_body_pose")[sl],
+                           transl=t("init_transl")[sl])
+        o1, _, _, l1 = fitter.fit_batch(one, t("j3d")[sl], conf_3d=conf[f], seq_ind=1, target_model_indices=idx, run_forward=False)
+        for key in ("global_orient", "body_pose", "betas", "transl"):
+            assert torch.equal(out[key][sl], o1[key]), (f, key)
+        assert torch.equal(loss[sl], l1)
+    # and it matters: shared confidences give a different fit
+    o2, _, _, _ = fitter.fit_batch(init, t("j3d"), conf_3d=conf[0], seq_ind=1, target_model_indices=idx, run_forward=False)
+    assert not torch.equal(o2["body_pose"][1:], out["body_pose"][1:])
+
+
 def test_camera_fitter_vertex_selected_joints_match_reference_golden(assets):
     """Camera-space fitter with GENERIC targets that include vertex-selected joints (model indices >= 24) in BOTH
-    stages (reference ``camera_space.py:199-210, 283-287``): the host-driven slow path must land on the reference's
+    stages (reference ``camera_space.py:199-210, 283-287``): the two-launch-per-iteration path inside ``k2b_fit_world`` must land on the reference's
     parameters, joints, vertices and re-evaluated loss at the usual 1e-4."""
     from keypoints2body_amd.core.fitters.camera_space import CameraSpaceFitter
     model, prior = assets

@@ -279,12 +279,21 @@ def test_fit_is_deterministic_and_frames_are_independent():
         assert torch.equal(a[k][2:5], sub[k])
 
 
-def test_vertex_joint_targets_are_rejected_loudly():
-    """k2b_fit_world itself fits kinematic joints only and says so; the fitter routes such targets through
-    k2b_vertex_term (tests/test_gpu_api.py::test_vertex_selected_joints_match_reference_golden)."""
+def test_vertex_joint_targets_through_the_c_call_match_reference_golden():
+    """k2b_fit_world with vertex-selected joints among the targets (two launches per iteration queued by the one call)
+    against the reference's end state; a target list WITHOUT a kinematic joint is refused."""
+    from keypoints2body_amd import native
     d = H.load_case("generic_vertex_joints")
+    out = H.native_fit(d)
+    for k in ("global_orient", "body_pose", "betas", "transl"):
+        assert np.abs(out[k].cpu().numpy() - d["out_" + k]).max() < 1e-4, k
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), d["out_loss"], rtol=2e-5)
+    idx = [i for i in H.case_indices(d) if i >= 24]
+    cols = [k for k, i in enumerate(H.case_indices(d)) if i >= 24]
+    cfg = native.default_fit_config()
     with pytest.raises(NotImplementedError):
-        H.native_fit(d)
+        native.fit_world(H.native_model(), H.native_prior(), cfg, idx, H.cuda(d["j3d"][:, cols]), None,
+                         H.cuda(d["init_global_orient"]), H.cuda(d["init_body_pose"]), H.cuda(d["init_betas"]), H.cuda(d["init_transl"]))
 
 
 def test_vertex_joint_term_gradient_matches_autograd():
