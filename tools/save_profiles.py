@@ -1,42 +1,53 @@
-"""Copy the measurement bundle of tools/profile_round.sh from gpurun_out/prof_<TAG>/ into profiles/
-(files the judge reads) and refresh profiles/traffic_r01.json.  usage: python tools/save_profiles.py TAG"""
+"""Copy the measurement bundle of tools/profile_round.sh from gpurun_out/prof_<TAG>/ into profiles/ (files the judge
+reads) and write profiles/traffic_<ROUND>.json.  usage: python tools/save_profiles.py TAG [ROUND=r02]"""
 import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 O = f'gpurun_out/prof_{tag}'
-for f in glob.glob('profiles/r01_final_*'): os.remove(f)
-shutil.copy(glob.glob(O + '/stats1024/*/*kernel_stats.csv')[0], 'profiles/r01_final_kernel_stats_1024f.csv')
-shutil.copy(glob.glob(O + '/stats4096/*/*kernel_stats.csv')[0], 'profiles/r01_final_kernel_stats_4096f.csv')
-for n in ('bench_1024', 'bench_4096', 'bench_1024_under_rocprof', 'bench_4096_under_rocprof'):
-    shutil.copy(f'{O}/{n}.json', f'profiles/r01_final_{n}.json')
-t = {"_doc": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for wide coalesced reads). KiB -> bytes."}
-for frames in ('1024', '4096'):
+P = f'profiles/{rnd}_final_'
+for f in glob.glob(P + '*'): os.remove(f)
+for d, n in (('stats4096', 'kernel_stats_4096seq'), ('stats1024', 'kernel_stats_1024f'), ('statsx1024', 'kernel_stats_smplx_1024f')):
+    shutil.copy(glob.glob(f'{O}/{d}/*/*kernel_stats.csv')[0], f'{P}{n}.csv')
+for n in ('bench_default', 'bench_1024', 'bench_smplx_1024', 'bench_smplx_4096', 'bench_default_under_rocprof',
+          'bench_1024_under_rocprof', 'bench_smplx_1024_under_rocprof'):
+    shutil.copy(f'{O}/{n}.json', f'{P}{n}.json')
+t = {"_doc": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of the bench command); "
+             "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for wide coalesced reads). KiB -> bytes. "
+             "lbs = pose set-up + tile kernel (full-mesh launch) + joint gather."}
+for key, pre in (('4096', ''), ('1024', ''), ('x1024', 'smplx_')):
     out, vals = [], {}
-    for name in (f'fetch{frames}', f'write{frames}'):
-        for d in glob.glob(f'{O}/{name}/*/*counter_collection.csv'):
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        for d in glob.glob(f'{O}/{c}_{key}/*/*counter_collection.csv'):
             for r in csv.DictReader(open(d)):
-                if 'k2b' in r['Kernel_Name']:
-                    kn = r['Kernel_Name'].split('(')[0]
-                    out.append((kn, r['Grid_Size'], r['Counter_Name'], r['Counter_Value']))
-                    if 'fit_world' in kn or 'lbs_mfma' in kn:
-                        vals.setdefault(('fit' if 'fit_world' in kn else 'lbs', r['Counter_Name']), []).append((int(r['Grid_Size']), float(r['Counter_Value'])))
+                if 'k2b' not in r['Kernel_Name']:
+                    continue
+                kn = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
+                out.append((kn, r['Grid_Size'], r['Counter_Name'], r['Counter_Value']))
+                kind = 'fit' if 'fit_' in kn else ('tile' if 'lbs_tile' in kn else ('pose' if 'pose_setup' in kn else ('gather' if 'gather' in kn else None)))
+                if kind:
+                    vals.setdefault((kind, r['Counter_Name']), []).append((int(r['Grid_Size']), float(r['Counter_Value'])))
     if not vals:
         continue
-    with open(f'profiles/r01_final_hbm_pmc_{frames}f.csv', 'w') as f:
+    frames = key.lstrip('x')
+    with open(f'{P}hbm_pmc_{pre}{frames}f.csv', 'w') as f:
         f.write('kernel,grid_size,counter,value_KiB\n')
         for o in out: f.write(','.join(o) + '\n')
-    # full-mesh launches only: the LBS kernel also runs on the 21 vertex-selected joints with a small grid
     avg = {}
-    for k, v in vals.items():
+    for k, v in vals.items():                  # the bench's launches only (largest grid of that kernel)
         gmax = max(g for g, _ in v)
         sel = [x for g, x in v if g == gmax]
         avg[k] = sum(sel) / len(sel)
-    print(frames, avg)
-    t[f"fit_frames_{frames}"] = int((2 * avg[('fit', 'FETCH_SIZE')] + avg[('fit', 'WRITE_SIZE')]) * 1024)
-    t[f"lbs_frames_{frames}"] = int((2 * avg[('lbs', 'FETCH_SIZE')] + avg[('lbs', 'WRITE_SIZE')]) * 1024)
-json.dump(t, open('profiles/traffic_r01.json', 'w'), indent=1)
+    print(key, {f"{a}/{b}": round(x) for (a, b), x in avg.items()})
+    g = lambda kind: 2 * avg.get((kind, 'FETCH_SIZE'), 0.0) + avg.get((kind, 'WRITE_SIZE'), 0.0)
+    t[f"{pre}fit_frames_{frames}"] = int(g('fit') * 1024)
+    t[f"{pre}lbs_frames_{frames}"] = int((g('tile') + g('pose') + g('gather')) * 1024)
+    t[f"{pre}lbs_tile_only_frames_{frames}"] = int(g('tile') * 1024)
+json.dump(t, open(f'profiles/traffic_{rnd}.json', 'w'), indent=1)
 print(t)
-for n in ('1024', '4096'):
-    rows = list(csv.DictReader(open(f'profiles/r01_final_kernel_stats_{n}f.csv')))
-    for r in rows[:4]: print(n, r['Name'][:60], r['Calls'], round(float(r['AverageNs']) / 1e3, 1), 'us')
-    b = json.load(open(f'profiles/r01_final_bench_{n}.json')); print(b['value'], b['ms_per_step'], b['roofline']['avg_launch_ms'], b['roofline']['frac'], b['roofline_lbs']['avg_launch_ms'], b['roofline_lbs']['frac'], b.get('cpu_baseline', {}).get('value'))
-    b = json.load(open(f'profiles/r01_final_bench_{n}_under_rocprof.json')); print('under rocprof', b['roofline']['avg_launch_ms'], b['roofline_lbs']['avg_launch_ms'])
+for n in ('4096seq', '1024f', 'smplx_1024f'):
+    rows = list(csv.DictReader(open(f'{P}kernel_stats_{n}.csv')))
+    for r in rows[:5]: print(n, r['Name'][:70], r['Calls'], round(float(r['AverageNs']) / 1e3, 1), 'us')
+for n in ('bench_default', 'bench_1024', 'bench_smplx_1024', 'bench_default_under_rocprof', 'bench_1024_under_rocprof'):
+    b = json.load(open(f'{P}{n}.json'))
+    print(n, b['value'], b['ms_per_step'], b['roofline']['avg_launch_ms'], b['roofline']['frac'], b['roofline_lbs']['avg_launch_ms'],
+          b['roofline_lbs']['frac'], b.get('cpu_baseline', {}).get('value'))
