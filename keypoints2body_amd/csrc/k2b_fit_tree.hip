@@ -48,14 +48,15 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int J = a.num_joints, NB = a.num_shape, Dv = a.prior_dims;
-    const int fr_raw = blockIdx.x * TW + wave;
+    const int tw = blockDim.x >> 6;                                // frames (waves) of this workgroup: 1..TW, by batch size
+    const int fr_raw = blockIdx.x * tw + wave;
     const bool frame_ok = fr_raw < a.num_frames;
     const int fr = frame_ok ? fr_raw : a.num_frames - 1;           // idle waves shadow the last frame and write nothing
 
     // ---- prior image -> LDS (whole workgroup) ---------------------------------------------------------------------------
-    for (int i = threadIdx.x; i < TMG * 16 * 64; i += 64 * TW)
+    for (int i = threadIdx.x; i < TMG * 16 * 64; i += blockDim.x)
         reinterpret_cast<float4*>(sA)[i] = reinterpret_cast<const float4*>(a.pA)[i];
-    for (int i = threadIdx.x; i < TMG * 64; i += 64 * TW) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
+    for (int i = threadIdx.x; i < TMG * 64; i += blockDim.x) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
     __syncthreads();
 
     // ---- per-lane constants ---------------------------------------------------------------------------------------------
@@ -297,7 +298,13 @@ hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
     if (a.num_joints > 64 || a.num_shape > 32 || a.prior_dims > 64 || a.num_gauss > TMG) return hipErrorInvalidValue;
     const size_t lds = (size_t)(TMG * 16 * 64 * 4 + 3 * TMG * 64) * sizeof(float);
-    const dim3 grid((a.num_frames + TW - 1) / TW), block(64 * TW);
+    // frames per workgroup: enough to cover the batch with one workgroup per CU (up to 8: two waves per SIMD); small
+    // batches get fewer waves per CU, so that every SIMD hosts at most one frame and all CUs work
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int tw = (a.num_frames + cus - 1) / cus;
+    tw = tw < 1 ? 1 : (tw > TW ? TW : tw);
+    const dim3 grid((a.num_frames + tw - 1) / tw), block(64 * tw);
     hipError_t e;
 #define K2B_TREE(NS_)                                                                                                  \
     do {                                                                                                               \

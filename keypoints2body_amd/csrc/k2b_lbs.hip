@@ -777,15 +777,25 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 // software pipeline over the entries: the A fragments of entry n + 1 are requested before the MFMAs of
                 // entry n, and entry n - 1 is folded into the outputs while the matrix pipe works on entry n (left to the
                 // compiler, every entry paid an LDS round trip and an MFMA drain: 2.6-4.2 k cycles for 72 MFMAs)
-                half8 af[2][NKT];
+                // (large trees: 2 x NKT fragment registers of look-ahead do not fit beside the resident W fragments - the SMPL-X
+                //  instantiation spilled 24 registers, and every scratch reload is a vmcnt(0) wait in the middle of the request
+                //  stream - so there the fragments of an entry are read right before its MFMAs; the SIMD partner covers the wait)
+                constexpr bool AHEAD = NKT <= 3;
+                half8 af[AHEAD ? 2 : 1][NKT];
                 floatx4 t[2][2];
+                if (AHEAD) {
 #pragma unroll
-                for (int k = 0; k < NKT; ++k) af[0][k] = rd(slot + fpair * NGP * 256, offA[k]);
+                    for (int k = 0; k < NKT; ++k) af[0][k] = rd(slot + fpair * NGP * 256, offA[k]);
+                }
 #pragma unroll
                 for (int ei = 0; ei <= EPS; ++ei) {
-                    if (ei + 1 < EPS) {
+                    if (AHEAD && ei + 1 < EPS) {
 #pragma unroll
                         for (int k = 0; k < NKT; ++k) af[(ei + 1) & 1][k] = rd(slot + ((ei + 1) * 2 + fpair) * NGP * 256, offA[k]);
+                    }
+                    if (!AHEAD && ei < EPS) {
+#pragma unroll
+                        for (int k = 0; k < NKT; ++k) af[0][k] = rd(slot + (ei * 2 + fpair) * NGP * 256, offA[k]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ei < EPS) {
@@ -794,7 +804,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
 #pragma unroll
                         for (int k = 0; k < NKT; ++k)
 #pragma unroll
-                            for (int v = 0; v < 2; ++v) t[ei & 1][v] = tile_mfma(af[ei & 1][k], wf[v][k], t[ei & 1][v]);
+                            for (int v = 0; v < 2; ++v) t[ei & 1][v] = tile_mfma(af[AHEAD ? (ei & 1) : 0][k], wf[v][k], t[ei & 1][v]);
                     }
                     if (ei > 0) {
                         const int nseq = ts * EPS + ei - 1, d = nseq / 3, r = nseq % 3;

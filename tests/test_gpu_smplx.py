@@ -129,3 +129,42 @@ def test_smplx_1024_frames_are_independent_and_deterministic():
     err0 = (m.lbs(z(3), z(162), z(20), tr0, want_vertices=False)[0][:, :55] - j3d).norm(dim=-1).mean()
     err1 = (jf[:, :55] - j3d).norm(dim=-1).mean()
     assert err1 < 0.35 * err0, (float(err0), float(err1))
+
+
+def test_smplx_through_the_public_sequence_api():
+    """optimize_params_sequence with body_model="smplx" and a 55-joint model: SMPLXData results in both sequence modes;
+    warm start = a chain of fit_frame calls, independent frames = rows of one batched fit (bit for bit: same launches)."""
+    import keypoints2body_amd as k2b
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.models.smpl_data import SMPLXData
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+    d = H.load_smplx_case("amass22_zero_init")
+    g = H.gmm_fixture()
+    c = H.body_consts_x()
+    model = BodyModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents, c.extra_vertex_ids)
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    fields = ("global_orient", "body_pose", "transl", "left_hand_pose", "right_hand_pose", "expression", "jaw_pose", "leye_pose",
+              "reye_pose", "betas")
+    init = SMPLXData(**{k: torch.tensor(d["init_" + k][:1]) for k in fields})
+    T = min(4, d["j3d"].shape[0])
+    seq = d["j3d"][:T]
+    mean = (torch.zeros(1, 66), torch.zeros(1, 10))
+    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=12, num_iters_followup=6, use_lbfgs=False,
+                              joints_category="AMASS", pose_prior=prior)
+    for warm in (True, False):
+        cfg = {"frame": {"use_lbfgs": False, "num_iters_first": 12, "num_iters_followup": 6}, "use_shape_optimization": False,
+               "use_previous_frame_init": warm, "fix_foot": False}
+        res = k2b.optimize_params_sequence(seq, init_params=init, body_model="smplx", joint_layout="AMASS", model=model, config=cfg,
+                                           pose_prior=prior, mean_params=mean)
+        assert len(res) == T and all(isinstance(r.params, SMPLXData) for r in res)
+        assert tuple(res[-1].vertices.shape) == (1, 10475, 3) and tuple(res[-1].joints.shape) == (1, 127, 3)
+        prev = init
+        for i in range(T):
+            want = fitter.fit_frame(prev if warm or i == 0 else init, torch.tensor(seq[i:i + 1]), conf_3d=torch.ones(22), seq_ind=i)
+            for k in fields:
+                assert torch.equal(getattr(res[i].params, k), getattr(want.params, k)), (warm, i, k)
+            assert torch.equal(res[i].vertices, want.vertices)
+            prev = want.params
+        # 22 AMASS targets give the fingers no gradient and no prior acts on them: they stay where they started
+        assert float(res[-1].params.left_hand_pose.abs().max()) == 0.0 and float(res[-1].params.body_pose.abs().max()) > 0.0
