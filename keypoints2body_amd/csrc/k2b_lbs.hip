@@ -551,12 +551,13 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
         unsigned char* slot = lds + (lq & 1) * kTileSlotBytes;
         if (ls < KX) {
             if (ls == 0) {        // new tile: offsets of the pieces at k-step 0 (lane i: piece p = lwv + 4 i)
-                const int p = lwv + 4 * (lane & 15);
+                const int ol = opaque_lane();             // (re-derived per tile: hoisted out of the tile loop these lane constants cost registers)
+                const int p = lwv + 4 * (ol & 15);
                 const int kh = p >> 3, ft = (p >> 1) & 3;                                            // X: [k-half][frame tile][hi/lo]
                 const int i2 = p - 16, kh2 = i2 / 24, r24 = i2 - kh2 * 24, v4 = r24 / 6, c = (r24 - v4 * 6) >> 1;   // Pd: [k-half][vertex tile][coord][hi/lo]
                 const int ftc = lw.fg * 4 + ft < ftiles ? lw.fg * 4 + ft : ftiles - 1;
                 const int vtc = lw.vg * 4 + v4 < vtiles ? lw.vg * 4 + v4 : vtiles - 1;
-                vpoff = lane < 4 ? (unsigned)(kh * ftiles + ftc) * kFragHalfs : (unsigned)((kh2 * 3 + c) * vtiles + vtc) * kFragHalfs;
+                vpoff = ol < 4 ? (unsigned)(kh * ftiles + ftc) * kFragHalfs : (unsigned)((kh2 * 3 + c) * vtiles + vtc) * kFragHalfs;
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
