@@ -177,7 +177,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     //   paired   two frame slots per wave (2w, 2w + 1): the tree of the first lives in lanes 0..31, that of
     //            the second in lanes 32..63; the row work runs once per slot.  Without split, wave w does
     //            both roles for its two slots.
-    const int slot0 = (PAIR ? 2 : 1) * (SPLIT ? (wave & 3) : wave);
+    // (split shape with one or two frames: the tree wave of slot s is wave 4 + ((s + 2) & 3), i.e. it sits on the SIMD of an idle
+    //  row slot instead of sharing its own row wave's SIMD - the two roles of a frame are co-critical and issue-bound together)
+    const bool spread = SPLIT && !PAIR && F <= 2 && wave >= 4;
+    const int slot0 = (PAIR ? 2 : 1) * (SPLIT ? (spread ? ((wave + 2) & 3) : (wave & 3)) : wave);
     const bool do_row = slot0 < F && (!SPLIT || wave < 4);     // rim of the prior, priors in row layout, Adam, results
     const bool do_tree = slot0 < F && (!SPLIT || wave >= 4);   // kinematics, joint loss, analytic backward
     // every wave must reach every barrier: a padding slot recomputes the last frame and skips the final stores
