@@ -31,6 +31,10 @@ def check_request(frame_cfg: FrameOptimizeConfig, body_model: str) -> None:
             "Current APIs support only joints3d.")
     if body_model not in OPTIMIZATION_BODY_MODELS:
         raise ValueError(f"Unsupported body_model: {body_model}")
+    if body_model in ("mano", "flame"):          # before any model file is opened or a launch is made
+        raise NotImplementedError(
+            f"body_model='{body_model}': the MANO/FLAME fitters (reference core/fitters/misc_models.py) are outside the "
+            "HIP engine's scope; SMPL-family models (smpl, smplh, smplx) are built")
 
 
 def canonicalize(xyz: torch.Tensor, conf: torch.Tensor, model_indices, in_layout: str, joint_layout: Optional[str],

@@ -66,6 +66,10 @@ class WorldSpaceFitter:
                  joints_category="SMPL24", device=None, pose_prior_num_gaussians=8,
                  pose_prior: Optional[MaxMixturePrior] = None):
         self.smpl: BodyModel = as_body_model(smpl_model, device=device)
+        if self.smpl.num_joints not in (24, 55):
+            raise NotImplementedError(
+                f"a body model with {self.smpl.num_joints} joints: the fit kernels are built for the 24-joint SMPL tree "
+                "(SMPL-H / SMPL-X parameter sets ride on it unfitted) and the 55-joint SMPL-X tree")
         self.device = self.smpl.device
         self.step_size = step_size
         self.num_iters_first = num_iters_first

@@ -131,3 +131,17 @@ def test_config_conversion_matches_reference_rules():
     assert cfgmod.sequence_config_from(None).frame.joints_category == "AMASS"
     with pytest.raises(TypeError):
         cfgmod.frame_config_from({"no_such_field": 1})
+
+
+def test_mano_and_flame_requests_are_rejected_before_anything_is_loaded():
+    """check_request (reference api/frame.py:60-75 accepts them; this engine's scope does not): NotImplementedError up
+    front, not a failure deep inside the fit."""
+    from keypoints2body_amd.api import common
+    from keypoints2body_amd.core.config import FrameOptimizeConfig
+    for name in ("mano", "flame"):
+        with pytest.raises(NotImplementedError):
+            common.check_request(FrameOptimizeConfig(), name)
+    for name in ("smpl", "smplh", "smplx"):
+        common.check_request(FrameOptimizeConfig(), name)
+    with pytest.raises(ValueError):
+        common.check_request(FrameOptimizeConfig(), "nope")
