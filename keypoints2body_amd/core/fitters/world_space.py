@@ -23,6 +23,8 @@ Differences, all deliberate and documented in DESIGN.md:
   reference (``world_space.py:126-151,215-229``), fitted by the tree kernel (``csrc/k2b_fit_tree.hip``) over one packed
   pose / shape vector.  The reference hands SMPL-X's 63-D body pose to its 69-D mixture, which raises (SURVEY.md N3);
   here the mixture is evaluated at ``[body_pose | 0 x 6]``, and hands are full axis-angle poses (``use_pca=False``).
+  Both branches: Adam fused, L-BFGS over evaluate-only launches of the tree kernel (one optimiser over the packed vectors:
+  L-BFGS only ever forms inner products of the flattened parameters, so the packing does not change it);
   With a 24-joint model, hand / face fields of ``SMPLHData`` / ``SMPLXData`` inputs are carried through unchanged;
 * vertex-selected joints (model joint index >= 24: smplx's "extra" joints, single mesh vertices): the fused
   kernel fits kinematic joints only, so ``k2b_fit_world`` then queues two launches per iteration (its kernel in
@@ -165,8 +167,6 @@ class WorldSpaceFitter:
         cfg = self._config(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
                            per_frame_conf and conf is not None and conf.dim() == 2)
         if smplx:
-            if self.use_lbfgs:
-                raise NotImplementedError("use_lbfgs=True with a 55-joint (SMPL-X) model: only the Adam branch is built for it")
             cfg.prior_pose_dims = 3 * self.smpl.NUM_BODY_JOINTS       # 63: what the mixture, bending and preserve terms see
             cfg.num_betas_prior = self.smpl.num_betas                 # 10: shape prior / freeze_betas leave the expression alone
         if self.use_lbfgs:
@@ -252,7 +252,10 @@ class WorldSpaceFitter:
             p = [go[sl].clone().requires_grad_(True), bp[sl].clone().requires_grad_(True),
                  tr[sl].clone().requires_grad_(True)]
             beta = be[sl].clone()
-            if not freeze_betas:
+            # (SMPL-X: the packed shape vector = betas | expression always joins the optimiser; with frozen betas their part of
+            #  the gradient is zero (``num_betas_prior``), which leaves them - and L-BFGS's inner products - untouched)
+            shape_in_optimiser = not freeze_betas or self.smpl.model_type == "smplx"
+            if shape_in_optimiser:
                 beta.requires_grad_(True)
                 p.append(beta)                         # parameter order of world_space.py:215-229
             cf = conf[sl].contiguous() if (conf is not None and conf.dim() == 2) else conf
@@ -271,7 +274,7 @@ class WorldSpaceFitter:
                 p[0].grad = g[:, 0:3].clone()
                 p[1].grad = g[:, 3:3 + D].clone()
                 p[2].grad = g[:, 3 + D + NB:].clone()
-                if not freeze_betas:
+                if shape_in_optimiser:
                     beta.grad = g[:, 3 + D:3 + D + NB].clone()
                 return r["loss"].sum()
 

@@ -168,3 +168,87 @@ def test_smplx_through_the_public_sequence_api():
             prev = want.params
         # 22 AMASS targets give the fingers no gradient and no prior acts on them: they stay where they started
         assert float(res[-1].params.left_hand_pose.abs().max()) == 0.0 and float(res[-1].params.body_pose.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("case,where", [("all55_zero_init", "out_"), ("all55_followup_frozen", "init_"), ("amass22_zero_init", "out_")])
+def test_smplx_evaluate_only_gradient_matches_autograd(case, where):
+    """What the tree kernel contributes to the L-BFGS branch: loss and analytic gradient at a given point (evaluate-only
+    launch: one iteration, step size 0) against torch autograd through the oracle's SMPL-X forward and loss, at the
+    reference's start / end points of the golden cases.  Gradient 5e-5 of its largest entry, loss 2e-5 relative."""
+    from keypoints2body_amd import native
+    from oracle.fit_torch import FitWeights, SMPLX_FIELDS, frame_losses
+    d = H.load_smplx_case(case)
+    seq_ind, freeze = int(d["seq_ind"]), bool(int(d["freeze_betas"]))
+    idx = [int(i) for i in d["target_model_indices"]] if d["target_model_indices"].size else list(range(22))
+    def autograd(dtype):
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=dtype)
+        p = {k: t(d[where + k]).requires_grad_(True) for k in SMPLX_FIELDS}
+        conf = t(d["conf"]) if int(d["has_conf"]) else torch.ones(len(idx), dtype=dtype)
+        prior = H.oracle_prior()
+        if dtype == torch.float64:
+            import copy
+            prior = copy.copy(prior)
+            prior.means, prior.precisions, prior.nll_weights = prior.means.double(), prior.precisions.double(), prior.nll_weights.double()
+        joints = H.oracle_model_x(double=dtype == torch.float64)(**p).joints
+        lf = frame_losses(p["body_pose"], t(d["init_body_pose"]), p["betas"], joints[:, idx], t(d["j3d"]), prior, conf, FitWeights(),
+                          preserve_on=seq_ind > 0)
+        lf.sum().backward()
+        g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).double().numpy() for k, v in p.items()}
+        if freeze:
+            g["betas"][:] = 0.0
+        return lf.detach().double().numpy(), np.concatenate([g["global_orient"]] + [g[k] for k, _ in POSE_FIELDS] +
+                                                             [g["betas"], g["expression"], g["transl"]], axis=1)
+
+    loss32, want32 = autograd(torch.float32)
+    loss64, want = autograd(torch.float64)
+
+    cfg = native.default_fit_config()
+    cfg.num_iters, cfg.step_size = 1, 0.0
+    cfg.pose_preserve_weight = 5.0 if seq_ind > 0 else 0.0
+    cfg.freeze_betas = int(freeze)
+    cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
+    go, pose, shape, tr = map(H.cuda, pack(d, where))
+    pres = H.cuda(np.concatenate([d["init_" + k] for k, _ in POSE_FIELDS], axis=1))
+    out = native.fit_world(H.native_model_x(), H.native_prior(), cfg, idx, H.cuda(d["j3d"]), H.cuda(d["conf"]) if int(d["has_conf"]) else None,
+                           go, pose, shape, tr, preserve_pose=pres, want_grad=True)
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), loss64, rtol=2e-5)
+    got = out["grad"].cpu().numpy().astype(np.float64)
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    err = (np.abs(got - want) / scale).max()
+    err32 = (np.abs(want32 - want) / scale).max()          # what fp32 autograd itself loses at this point (near a minimum the
+                                                           # gradient is a small difference of large terms)
+    assert err < max(5e-5, 2.0 * err32), f"{case}/{where}: gradient off by {err:.2e} of its largest entry (fp32 autograd: {err32:.2e})"
+    print(f"smplx gradient {case}/{where}: HIP {err:.2e}, fp32 autograd {err32:.2e} of the largest entry (float64 reference)")
+    for k in ("global_orient", "body_pose", "betas", "transl"):          # an evaluate-only launch moves nothing
+        assert torch.equal(out[k], {"global_orient": go, "body_pose": pose, "betas": shape, "transl": tr}[k])
+
+
+def test_smplx_lbfgs_branch_runs_on_evaluate_only_launches():
+    """use_lbfgs=True (the reference default, world_space.py:231-247) with a 55-joint model: torch.optim.LBFGS over the packed
+    parameter vectors, every closure call one evaluate-only launch of the tree kernel.  No golden (the reference cannot run
+    SMPL-X with its prior, SURVEY N3, and the mode is chaotic): it must beat the 30 Adam steps' loss from the same
+    start, keep frozen betas bit for bit and leave the untargeted fingers alone."""
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.models.smpl_data import SMPLXData
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+    d = H.load_smplx_case("amass22_zero_init")
+    g = H.gmm_fixture()
+    c = H.body_consts_x()
+    model = BodyModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents, c.extra_vertex_ids)
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    fields = ("global_orient", "body_pose", "transl", "left_hand_pose", "right_hand_pose", "expression", "jaw_pose", "leye_pose",
+              "reye_pose", "betas")
+    init = SMPLXData(**{k: torch.tensor(d["init_" + k][:2]) for k in fields})
+    j3d = torch.tensor(d["j3d"][:2])
+    kw = dict(step_size=1e-2, num_iters_first=30, num_iters_followup=30, joints_category="AMASS", pose_prior=prior)
+    adam = WorldSpaceFitter(model, use_lbfgs=False, **kw).fit_frame(init, j3d, seq_ind=0)
+    for freeze in (False, True):
+        res = WorldSpaceFitter(model, use_lbfgs=True, **kw).fit_frame(init, j3d, seq_ind=1 if freeze else 0, freeze_betas=freeze)
+        assert isinstance(res.params, SMPLXData) and torch.isfinite(res.loss)
+        assert all(torch.isfinite(getattr(res.params, k)).all() for k in fields)
+        if freeze:
+            assert torch.equal(res.params.betas.cpu(), init.betas)
+        else:
+            assert float(res.loss) < float(adam.loss)
+        assert float(res.params.left_hand_pose.abs().max()) == 0.0
