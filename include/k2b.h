@@ -184,8 +184,8 @@ int k2b_fit_world(const k2b_model *model, const k2b_prior *prior, const k2b_fit_
  *   j3d  dev [S][T][K][3], conf dev [K] or [S][T][K] (conf_per_frame)
  *   *_in dev [S][...]: start of frame 0 of every sequence
  *   *_out dev [S][T][...], loss_out dev [S][T]: every frame's fitted parameters / last-iteration loss
- * 24-joint models with a full-width mixture only (others: K2B_ERR_UNSUPPORTED - fit frame by frame);
- * cfg->transl_prior_weight must be 0.
+ * Kinematic targets only (vertex-selected joints: K2B_ERR_UNSUPPORTED - fit frame by frame); cfg->transl_prior_weight
+ * must be 0.  24-joint models run the split shape of the fused kernel, larger trees (SMPL-X) the tree kernel.
  * ------------------------------------------------------------------------------- */
 int k2b_fit_sequence(const k2b_model *model, const k2b_prior *prior, const k2b_fit_config *cfg,
                      int32_t num_sequences, int32_t frames_per_sequence, int32_t followup_iters,

@@ -5,7 +5,7 @@ Two execution modes, both with the reference's per-frame semantics:
 
 * ``use_previous_frame_init=True`` (reference default): every frame starts from the previous
   frame's result, an inherently sequential chain (``api/sequence.py:280-281``).  World mode, Adam branch,
-  24-joint model, kinematic targets: the WHOLE chain is one launch (``k2b_fit_sequence``: the frame loop runs
+  kinematic targets (SMPL and SMPL-X): the WHOLE chain is one launch (``k2b_fit_sequence``: the frame loop runs
   inside the kernel, parameters and optimiser state never leave registers) followed by one final forward over
   all frames; any other configuration: one single-frame call per frame;
 * ``use_previous_frame_init=False``: every frame starts from the same initial parameters, so

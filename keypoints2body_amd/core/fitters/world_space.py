@@ -179,9 +179,9 @@ class WorldSpaceFitter:
         return out, joints, verts, out["loss"]
 
     def chain_supported(self, target_model_indices=None) -> bool:
-        """Whether ``fit_chain`` can run this fitter's sequence mode in one launch: Adam branch, 24-joint model,
-        kinematic targets only (otherwise the caller fits frame by frame)."""
-        if self.use_lbfgs or self.smpl.num_joints != 24:
+        """Whether ``fit_chain`` can run this fitter's sequence mode in one launch: Adam branch, kinematic targets only
+        (otherwise the caller fits frame by frame)."""
+        if self.use_lbfgs:
             return False
         idx = self.smpl_index if target_model_indices is None else torch.as_tensor(target_model_indices).reshape(-1).tolist()
         return idx is not None and all(int(i) < self.smpl.num_joints for i in idx)
@@ -195,12 +195,14 @@ class WorldSpaceFitter:
         ``num_iters_followup`` iterations.  ``conf_3d``: (K,) or per frame (T, K) as the sequence API passes it.
         Returns ``(params: dict of (T,.) tensors, joints, vertices, per_frame_loss)`` like ``fit_batch``."""
         if not self.chain_supported(target_model_indices):
-            raise NotImplementedError("fit_chain: Adam branch with a 24-joint model and kinematic targets only")
+            raise NotImplementedError("fit_chain: Adam branch and kinematic targets only")
         per_frame = conf_3d is not None and torch.as_tensor(conf_3d).dim() == 2
         go, bp, be, tr, model_idx, tgt, conf = self._prepare(init_params, j3d, conf_3d, target_model_indices, per_frame,
                                                              num_init=1)
         cfg = self._config(0, joint_loss_weight, pose_preserve_weight, freeze_betas, per_frame)
         cfg.pose_preserve_weight = float(pose_preserve_weight)      # frames >= 1 (frame 0 has no preserve term)
+        if self.smpl.model_type == "smplx":
+            cfg.prior_pose_dims, cfg.num_betas_prior = 3 * self.smpl.NUM_BODY_JOINTS, self.smpl.num_betas
         T = tgt.shape[0]
         out = native.fit_sequence(self.smpl.native, self.pose_prior.native, cfg, int(self.num_iters_followup), model_idx,
                                   tgt.unsqueeze(0), None if conf is None else (conf.unsqueeze(0) if per_frame else conf),

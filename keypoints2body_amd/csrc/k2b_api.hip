@@ -600,7 +600,7 @@ int folded_prior(k2b_prior* p, int Dv, k2b_prior::Folded* out) {
 int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int prior_dims, int32_t B, int32_t K,
              const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in, const float* bp_in,
              const float* be_in, const float* tr_in, const float* preserve, const float* tr_prior, float* go_out, float* bp_out,
-             float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream) {
+             float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream, int chain_len = 1, int chain_iters = 0) {
     const int J = model->J, NB = model->NB;
     if (prior_dims < 3 || prior_dims > 64 || prior_dims % 3 != 0 || prior_dims > prior->D || prior_dims > 3 * (J - 1))
         return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the tree kernel takes a prior over the first 3..63 body-pose dimensions "
@@ -637,7 +637,11 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
     k2b_prior::Folded f;
     if (const int rc = folded_prior(prior, prior_dims, &f); rc != K2B_OK) return rc;
     float2* coef = nullptr;
-    if (const int rc = adam_table(model, cfg, (hipStream_t)stream, &coef); rc != K2B_OK) return rc;
+    {   // a chain's follow-up frames restart the optimiser: one table long enough for both counts, each reads its prefix
+        k2b_fit_config tc = *cfg;
+        if (chain_len > 1 && chain_iters > tc.num_iters) tc.num_iters = chain_iters;
+        if (const int rc = adam_table(model, &tc, (hipStream_t)stream, &coef); rc != K2B_OK) return rc;
+    }
     {   // prior columns of the lane table (depend on prior_dims): uploaded once per model and value
         static thread_local std::pair<const k2b_model*, int> last{nullptr, -1};
         if (last.first != model || last.second != prior_dims) {
@@ -674,6 +678,8 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
     a.freeze_betas = cfg->freeze_betas ? 1 : 0;
     a.num_betas_prior = cfg->num_betas_prior > 0 ? (cfg->num_betas_prior < NB ? cfg->num_betas_prior : NB) : NB;
     a.opt_mask = cfg->optimize_mask & 15;
+    a.chain_len = chain_len > 1 ? chain_len : 1;
+    a.chain_iters = chain_iters;
     HIP_TRY(k2b::launch_fit_tree(a, (hipStream_t)stream));
     return K2B_OK;
 }
@@ -759,15 +765,13 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     const int prior_dims = cfg->prior_pose_dims > 0 ? cfg->prior_pose_dims : (prior->D < pose_dims_all ? prior->D : pose_dims_all);
     const bool small_tree = model->fit_ok && prior->D == pose_dims_all && prior_dims == pose_dims_all &&
                             (cfg->num_betas_prior == 0 || cfg->num_betas_prior == model->NB);
-    if (!small_tree && chain_len > 1)
-        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_sequence: warm-start chains are built for the 24-joint kernel only (fit frame by frame)");
     if (chain_len > 1 && (chain_iters < 1 || chain_iters > (1 << 20)))
         return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_sequence: followup_iters=%d", chain_iters);
     if (chain_len > 1 && (preserve || tr_prior || grad_out || cfg->transl_prior_weight != 0.0f))
         return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_sequence: no explicit preserve pose, translation prior or gradient output in a chain");
     if (!small_tree)
         return fit_tree(model, const_cast<k2b_prior*>(prior), cfg, prior_dims, B, K, model_joint_index, j3d, conf, go_in, bp_in, be_in, tr_in,
-                        preserve, tr_prior, go_out, bp_out, be_out, tr_out, loss_out, grad_out, stream);
+                        preserve, tr_prior, go_out, bp_out, be_out, tr_out, loss_out, grad_out, stream, chain_len, chain_iters);
     if (B < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_frames=%d", B);
     if (K < 1 || K > model->J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: num_targets=%d out of range", K);
     if (!model_joint_index) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index is NULL");

@@ -36,7 +36,7 @@ __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 
 
 __device__ __forceinline__ double shfl64(double v, int src) { return bperm64(src << 2, v); }
 
-template <int NS>                        // capacity for shape coefficients (betas | expression): 16 or 32
+template <int NS, bool CHAIN>            // NS: capacity for shape coefficients (betas | expression): 16 or 32; CHAIN: warm-start chains
 __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tlds[];
     // [M][16][64][4] A | [M][64] h | [M][64] b | [M][64] mu
@@ -79,9 +79,10 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
     const int tk = isJ ? a.lane_target[lane] : -1;
     float ty0 = 0.f, ty1 = 0.f, ty2 = 0.f, wconf = 0.f;
     if (tk >= 0) {
-        const float* y = a.j3d + ((size_t)fr * a.num_targets + tk) * 3;
+        const size_t f0 = (size_t)fr * (CHAIN ? a.chain_len : 1);
+        const float* y = a.j3d + (f0 * a.num_targets + tk) * 3;
         ty0 = y[0]; ty1 = y[1]; ty2 = y[2];
-        const float cf = a.conf ? a.conf[(a.conf_per_frame ? (size_t)fr * a.num_targets : 0) + tk] : 1.0f;
+        const float cf = a.conf ? a.conf[(a.conf_per_frame ? f0 * a.num_targets : 0) + tk] : 1.0f;
         wconf = (a.joint_w * a.joint_w) * (cf * cf);
     }
     const float s2 = a.sigma * a.sigma;
@@ -102,18 +103,43 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
     const bool opt_tr = lane < 3 && (a.opt_mask & 8);
     // prior-layout constants (lane i = prior dimension i)
     const bool isP = lane < Dv;
-    const float pres0 = isP ? (a.preserve ? a.preserve[(size_t)fr * D + lane] : a.bp_in[(size_t)fr * D + lane]) : 0.f;
+    float pres0 = isP ? (a.preserve ? a.preserve[(size_t)fr * D + lane] : a.bp_in[(size_t)fr * D + lane]) : 0.f;
     float ang_s = 0.f;                           // sign of the bending prior on this dimension (0: none)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (a.angle_index[i] == lane && isP) ang_s = a.angle_sign[i];
-    const float wpp = a.pose_prior_w * a.pose_prior_w, wang = a.angle_w * a.angle_w, wsh = a.shape_w * a.shape_w,
-                wpr = a.preserve_w * a.preserve_w;
+    // warm-start chain (a.chain_len > 1): this wave carries a SEQUENCE; step 0 is its first frame (no preserve term, num_iters
+    // iterations), every later step starts from the previous result, preserves it and runs chain_iters iterations with a
+    // fresh optimiser state (reference api/sequence.py:214-281, world_space.py:159,211,214); frame rows fr * chain_len + step
+    // (a template parameter: the plain launch keeps its register budget - with the chain's mutable state in the same
+    //  instantiation the SMPL-X kernel went from 247 registers to 256 + 40 bytes of scratch)
+    const int chain = CHAIN ? a.chain_len : 1;
+    const float wpp = a.pose_prior_w * a.pose_prior_w, wang = a.angle_w * a.angle_w, wsh = a.shape_w * a.shape_w;
+    float wpr = CHAIN ? 0.f : a.preserve_w * a.preserve_w;
 
     float loss_total = 0.f;
     float gth[3] = {0.f, 0.f, 0.f}, gsh = 0.f, gtr = 0.f;
 
-    for (int it = 0; it < a.num_iters; ++it) {
+    for (int step = 0; step < chain; ++step) {
+    const int nit = step == 0 ? a.num_iters : a.chain_iters;
+    if (CHAIN && step > 0) {
+        if (tk >= 0) {                           // targets of this step's frame
+            const size_t ft = (size_t)fr * chain + step;
+            const float* y = a.j3d + (ft * a.num_targets + tk) * 3;
+            ty0 = y[0]; ty1 = y[1]; ty2 = y[2];
+            const float cf = a.conf ? a.conf[(a.conf_per_frame ? ft * a.num_targets : 0) + tk] : 1.0f;
+            wconf = (a.joint_w * a.joint_w) * (cf * cf);
+        }
+        {                                        // preserve the previous result (prior layout), fresh Adam state
+            const float c0 = shfl(th[0], psrc < 0 ? 0 : psrc), c1 = shfl(th[1], psrc < 0 ? 0 : psrc), c2 = shfl(th[2], psrc < 0 ? 0 : psrc);
+            pres0 = psrc < 0 ? 0.f : (pcomp == 0 ? c0 : (pcomp == 1 ? c1 : c2));
+        }
+        wpr = a.preserve_w * a.preserve_w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mth[c] = vth[c] = 0.f;
+        msh = vsh = mtr = vtr = 0.f;
+    }
+    for (int it = 0; it < nit; ++it) {
         // ---- rest offset from the parent: d = dt + dd . shape -------------------------------------------------------------
         float dx = dtx, dy = dty, dz = dtz;
 #pragma unroll
@@ -271,15 +297,20 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         adam(sh, msh, vsh, gsh, opt_sh);
         adam(tr, mtr, vtr, gtr, opt_tr);
     }
+    // results of this step's frame (a plain launch has one step and row fr)
+    if (frame_ok) {
+        const size_t fo = CHAIN ? (size_t)fr * chain + step : (size_t)fr;
+        if (isJ) {
+            float* dst = joint == 0 ? a.go_out + fo * 3 : a.bp_out + fo * D + 3 * (joint - 1);
+            dst[0] = th[0]; dst[1] = th[1]; dst[2] = th[2];
+        }
+        if (lane < NB) a.be_out[fo * NB + lane] = sh;
+        if (lane < 3) a.tr_out[fo * 3 + lane] = tr;
+        if (lane == 0 && a.loss_out) a.loss_out[fo] = loss_total;
+    }
+    }  // chain steps
 
     if (!frame_ok) return;
-    if (isJ) {
-        float* dst = joint == 0 ? a.go_out + (size_t)fr * 3 : a.bp_out + (size_t)fr * D + 3 * (joint - 1);
-        dst[0] = th[0]; dst[1] = th[1]; dst[2] = th[2];
-    }
-    if (lane < NB) a.be_out[(size_t)fr * NB + lane] = sh;
-    if (lane < 3) a.tr_out[(size_t)fr * 3 + lane] = tr;
-    if (lane == 0 && a.loss_out) a.loss_out[fr] = loss_total;
     if (a.grad_out) {
         const int P = 3 + D + NB + 3;
         float* go = a.grad_out + (size_t)fr * P;
@@ -306,17 +337,19 @@ hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream) {
     tw = tw < 1 ? 1 : (tw > TW ? TW : tw);
     const dim3 grid((a.num_frames + tw - 1) / tw), block(64 * tw);
     hipError_t e;
-#define K2B_TREE(NS_)                                                                                                  \
+#define K2B_TREE(NS_, CH_)                                                                                             \
     do {                                                                                                               \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            e = hipFuncSetAttribute((const void*)k2b_fit_tree_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            e = hipFuncSetAttribute((const void*)k2b_fit_tree_kernel<NS_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                             \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((k2b_fit_tree_kernel<NS_>), grid, block, lds, stream, a);                                   \
+        hipLaunchKernelGGL((k2b_fit_tree_kernel<NS_, CH_>), grid, block, lds, stream, a);                              \
     } while (0)
-    if (a.num_shape <= 16) K2B_TREE(16); else K2B_TREE(32);
+    const bool chain = a.chain_len > 1;
+    if (a.num_shape <= 16) { if (chain) K2B_TREE(16, true); else K2B_TREE(16, false); }
+    else { if (chain) K2B_TREE(32, true); else K2B_TREE(32, false); }
 #undef K2B_TREE
     return hipGetLastError();
 }

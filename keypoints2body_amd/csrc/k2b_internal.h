@@ -95,6 +95,7 @@ struct FitTreeArgs {
     int opt_mask;               // bit 0 global_orient, 1 body_pose, 2 shape coefficients, 3 transl
     int angle_index[4];
     float angle_sign[4];
+    int chain_len, chain_iters;  // warm-start chain: num_frames SEQUENCES of chain_len frames each (<= 1: independent frames)
 };
 hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream);
 

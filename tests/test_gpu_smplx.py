@@ -160,7 +160,7 @@ def test_smplx_through_the_public_sequence_api():
         assert len(res) == T and all(isinstance(r.params, SMPLXData) for r in res)
         assert tuple(res[-1].vertices.shape) == (1, 10475, 3) and tuple(res[-1].joints.shape) == (1, 127, 3)
         prev = init
-        for i in range(T):
+        for i in range(T):      # (warm start: the API runs the whole chain as ONE launch of the tree kernel - same bits as frame by frame)
             want = fitter.fit_frame(prev if warm or i == 0 else init, torch.tensor(seq[i:i + 1]), conf_3d=torch.ones(22), seq_ind=i)
             for k in fields:
                 assert torch.equal(getattr(res[i].params, k), getattr(want.params, k)), (warm, i, k)
@@ -252,3 +252,36 @@ def test_smplx_lbfgs_branch_runs_on_evaluate_only_launches():
         else:
             assert float(res.loss) < float(adam.loss)
         assert float(res.params.left_hand_pose.abs().max()) == 0.0
+
+
+def test_smplx_chain_launch_equals_frame_by_frame_launches():
+    """k2b_fit_sequence on the 55-joint tree kernel: many chains side by side, per-frame confidences, frozen betas, follow-up
+    count larger than the first frame's - bit-identical to host-driven per-frame launches."""
+    from keypoints2body_amd import native, synthetic
+    import copy
+    m, pr = H.native_model_x(), H.native_prior()
+    for S, T, first, follow, freeze in ((1, 5, 12, 6, False), (37, 3, 5, 9, True)):
+        p = synthetic.make_poses_x(S * T, seed=S)
+        pose = np.concatenate([getattr(p, k) for k, _ in POSE_FIELDS], axis=1)
+        shape = np.concatenate([p.betas, p.expression], axis=1)
+        j, _ = m.lbs(H.cuda(p.global_orient), H.cuda(pose), H.cuda(shape), H.cuda(p.transl), want_vertices=False)
+        j3d = j[:, :55].reshape(S, T, 55, 3).contiguous()
+        conf = H.cuda(np.random.default_rng(S).uniform(0.5, 1.5, (S, T, 55)).astype(np.float32))
+        z = lambda c: torch.zeros(S, c, device="cuda")
+        go, bp, be, tr = z(3), z(162), 0.1 * torch.ones(S, 20, device="cuda"), j3d[:, 0, 0].contiguous()
+        cfg = native.default_fit_config()
+        cfg.num_iters, cfg.pose_preserve_weight, cfg.freeze_betas, cfg.conf_per_frame = first, 5.0, int(freeze), 1
+        cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
+        got = native.fit_sequence(m, pr, cfg, follow, list(range(55)), j3d, conf, go, bp, be, tr)
+        cur, want = (go, bp, be, tr), {k: [] for k in got}
+        for t in range(T):
+            c = copy.copy(cfg)
+            c.num_iters, c.pose_preserve_weight = (first, 0.0) if t == 0 else (follow, 5.0)
+            o = native.fit_world(m, pr, c, list(range(55)), j3d[:, t].contiguous(), conf[:, t].contiguous(), *cur)
+            for k in want:
+                want[k].append(o[k])
+            cur = (o["global_orient"], o["body_pose"], o["betas"], o["transl"])
+        for k in got:
+            assert torch.equal(got[k], torch.stack(want[k], dim=1)), (S, T, k)
+        if freeze:
+            assert torch.equal(got["betas"][:, :, :10], be[:, None, :10].expand(-1, T, -1))
