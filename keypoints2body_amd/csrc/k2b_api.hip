@@ -663,7 +663,8 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
     a.num_rounds = 0;
     while ((1 << a.num_rounds) < maxd + 1) ++a.num_rounds;
     if (J > 63 || a.num_rounds > 4) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the tree kernel takes up to 63 joints and depth 15");
-    a.pA = f.pA; a.ph = f.ph; a.pb = f.pb; a.pmu = f.pmu; a.pcl = f.pcl;
+    a.pfrag = prior->frag32; a.ph = f.ph; a.pb = f.pb; a.pmu = f.pmu; a.pcl = f.pcl;
+    for (int m = 0; m < k2b::kPriorMaxGauss; ++m) a.inv_scale[m] = prior->inv_scale[m];
     a.num_gauss = prior->M; a.prior_dims = prior_dims;
     a.num_frames = B; a.num_targets = K;
     a.j3d = j3d; a.conf = conf; a.conf_per_frame = cfg->conf_per_frame ? 1 : 0;

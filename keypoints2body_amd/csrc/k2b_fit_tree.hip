@@ -16,9 +16,14 @@
 //     at [theta_body(63) | 0 x 6].  With the six padded dimensions constant the quadratic form folds, ON THE HOST,
 //     into a D_v-dimensional one:  q_m = d^T A_m d + 2 b_m^T d + c_m  (d = theta_v - mu_v; A = P_vv, b = P_vc d_c,
 //     c = d_c^T P_cc d_c, d_c = -mu_c), and y' = A theta_v + h (h = b - A mu_v) is both the gradient of 0.5 q and,
-//     through q = d.(y' + b) + c, the value.  The eight components' A (8 x 16 KiB) are resident in LDS, shared by the
-//     8 frames of a workgroup; theta_v is broadcast from scalar registers (v_readlane), so a component costs 16
-//     ds_read_b128 + 64 FMAs per lane.
+//     through q = d.(y' + b) + c, the value.  A theta_v runs on the MATRIX CORES, for all frames of the workgroup at once:
+//     A_m = the leading block of the 64 x 64 core of P_m, whose f16 hi/lo fragments k2b_fit.hip already uses (with
+//     theta_j = 0 for j >= D_v the core's extra columns contribute nothing, its extra rows are never read).  The eight
+//     components' fragments (128 KiB) are resident in LDS; wave w owns the components w, w + tw, ...: it multiplies them
+//     with the f16 hi/lo strips of theta_v that every frame's wave published (three v_mfma_f32_16x16x32_f16 products
+//     per tile, one frame per MFMA column), adds h, reduces q per frame and hands y' and q back through LDS; two
+//     workgroup barriers per iteration.  (The first version did it on the vector ALU, per frame: 128 ds_read_b128 +
+//     512 FMAs + 64 v_readlane per iteration - half of the kernel's instructions.)
 // Loss terms, Adam arithmetic and the "loss of the last iteration before its step" convention are those of
 // k2b_fit.hip (oracle: oracle/fit_torch.py; goldens: tests/golden/smplx_fit_*.npz).
 #include "k2b_internal.h"
@@ -31,19 +36,25 @@ namespace {
 constexpr int TW = 8;                    // frames (waves) per workgroup
 constexpr int TMG = kPriorMaxGauss;      // 8 mixture components
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 
 __device__ __forceinline__ double shfl64(double v, int src) { return bperm64(src << 2, v); }
 
-template <int NS, bool CHAIN>            // NS: capacity for shape coefficients (betas | expression): 16 or 32; CHAIN: warm-start chains
+template <int NS, bool CHAIN>            // NS: capacity for shape coefficients (betas | expression): 16, 20 or 32; CHAIN: warm-start chains
 __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tlds[];
-    // [M][16][64][4] A | [M][64] h | [M][64] b | [M][64] mu
-    float* const sA = tlds;
-    float* const sH = sA + TMG * 16 * 64 * 4;
+    // [8][16][64] half8 A fragments (128 KiB) | [M][64] h | [M][64] b | [M][64] mu | [TW][64] theta_v fp32 |
+    // [TW][hi 64 | lo 64] theta_v f16 | [TW][M][64] y' | [TW][M] q
+    const half8* const sFrag = reinterpret_cast<const half8*>(tlds);
+    float* const sH = tlds + TMG * 16 * 64 * 4;
     float* const sB = sH + TMG * 64;
     float* const sMu = sB + TMG * 64;
+    float* const sTh = sMu + TMG * 64;
+    _Float16* const sTh16 = reinterpret_cast<_Float16*>(sTh + TW * 64);
+    float* const sY = sTh + TW * 64 + TW * 64;           // (TW x 128 halfs = TW x 64 floats)
+    float* const sQ = sY + TW * TMG * 64;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -55,7 +66,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
 
     // ---- prior image -> LDS (whole workgroup) ---------------------------------------------------------------------------
     for (int i = threadIdx.x; i < TMG * 16 * 64; i += blockDim.x)
-        reinterpret_cast<float4*>(sA)[i] = reinterpret_cast<const float4*>(a.pA)[i];
+        reinterpret_cast<float4*>(tlds)[i] = reinterpret_cast<const float4*>(a.pfrag)[i];
     for (int i = threadIdx.x; i < TMG * 64; i += blockDim.x) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
     __syncthreads();
 
@@ -139,7 +150,63 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         for (int c = 0; c < 3; ++c) mth[c] = vth[c] = 0.f;
         msh = vsh = mtr = vtr = 0.f;
     }
+    const bool use_gmm = wpp > 0.f;              // (uniform over the launch: the barriers below are taken by every wave or by none)
+    const int cn = lane & 15, cg = lane >> 4;    // MFMA lane: column (frame slot of the workgroup) and k / row group
+    const int cslot = cn < tw ? cn : tw - 1;     // columns beyond the workgroup's frames repeat the last slot
     for (int it = 0; it < nit; ++it) {
+        // ---- body pose in prior layout (lane i = prior dimension i); published for the component role ------------------------------
+        float thv;
+        {
+            const float c0 = shfl(th[0], psrc < 0 ? 0 : psrc), c1 = shfl(th[1], psrc < 0 ? 0 : psrc), c2 = shfl(th[2], psrc < 0 ? 0 : psrc);
+            thv = psrc < 0 ? 0.f : (pcomp == 0 ? c0 : (pcomp == 1 ? c1 : c2));
+        }
+        if (use_gmm) {
+            const _Float16 hh = (_Float16)thv;
+            sTh[wave * 64 + lane] = thv;
+            sTh16[wave * 128 + lane] = hh;
+            sTh16[wave * 128 + 64 + lane] = (_Float16)(thv - (float)hh);
+            __syncthreads();
+            // component role: y' = A theta_v + h and q = d . (y' + b) of the components w, w + tw, ... for every frame slot
+            const half8 bh0 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 8 * cg);
+            const half8 bh1 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 32 + 8 * cg);
+            const half8 bl0 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 64 + 8 * cg);
+            const half8 bl1 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 96 + 8 * cg);
+            for (int c = wave; c < TMG; c += tw) {
+                const float inv_scale = a.inv_scale[c];
+                float qp = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const half8* fr4 = sFrag + ((c * 4 + t) * 4) * 64 + lane;
+                    const half8 ph0 = fr4[0], ph1 = fr4[64], pl0 = fr4[128], pl1 = fr4[192];
+                    floatx4 acc = {0.f, 0.f, 0.f, 0.f};              // small terms first, as k2b_fit.hip does
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl0, bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl1, bh1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph0, bl0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph1, bl1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph0, bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph1, bh1, acc, 0, 0, 0);
+                    // accumulator layout: lane (n = l & 15, g = l >> 4), register i <-> row 16 t + 4 g + i, column n
+                    const int r0 = 16 * t + 4 * cg;
+                    const floatx4 th4 = *reinterpret_cast<const floatx4*>(sTh + cslot * 64 + r0);
+                    const floatx4 mu4 = *reinterpret_cast<const floatx4*>(sMu + c * 64 + r0);
+                    const floatx4 h4 = *reinterpret_cast<const floatx4*>(sH + c * 64 + r0);
+                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(sB + c * 64 + r0);
+                    floatx4 y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        y[i] = acc[i] * inv_scale + h4[i];
+                        qp += (th4[i] - mu4[i]) * (y[i] + b4[i]);     // (rows >= D_v: theta = mu = h = b = 0)
+                    }
+                    *reinterpret_cast<floatx4*>(sY + (cslot * TMG + c) * 64 + r0) = y;
+                }
+                qp = pair_sum32(qp);
+                qp = pair_sum16(qp);                                  // summed over the four row groups
+                sQ[cslot * TMG + c] = qp;
+            }
+            // keep the B fragments live past the last MFMA (ROCm 7.2 register allocation, see k2b_fit.hip)
+            asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+            __syncthreads();
+        }
         // ---- rest offset from the parent: d = dt + dd . shape -------------------------------------------------------------
         float dx = dtx, dy = dty, dz = dtz;
 #pragma unroll
@@ -212,11 +279,13 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         // shape coefficients through the rest offsets: g_k = sum_l gd_l . dd_l[:, k]  (+ shape prior on the betas)
         gsh = 0.f;
 #pragma unroll
-        for (int blk = 0; blk < NS / 16; ++blk) {        // 16 coefficients per butterfly: lane l ends with the total of k = (l >> 2) & 15
+        for (int blk = 0; blk < (NS + 15) / 16; ++blk) { // 16 coefficients per butterfly: lane l ends with the total of k = (l >> 2) & 15
             float part[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                part[k] = isJ ? gd.x * dd[0][16 * blk + k] + gd.y * dd[1][16 * blk + k] + gd.z * dd[2][16 * blk + k] : 0.f;
+            for (int k = 0; k < 16; ++k) {
+                const int kk = 16 * blk + k < NS ? 16 * blk + k : 0;                 // (beyond the capacity: compile-time zeros)
+                part[k] = (16 * blk + k < NS && isJ) ? gd.x * dd[0][kk] + gd.y * dd[1][kk] + gd.z * dd[2][kk] : 0.f;
+            }
             const float tot = butterfly16_sum(part, lane);
             const float mine = shfl(tot, (lane & 15) << 2);          // coefficient 16 blk + (lane & 15) sits in lanes 4 k .. 4 k + 3
             if ((lane >> 4) == blk) gsh = mine;
@@ -225,43 +294,19 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         if (lane < a.num_betas_prior) { lsh = wsh * sh * sh; gsh += 2.f * wsh * sh; }
 
         // ---- priors on the body pose, prior layout (lane i = prior dimension i) ----------------------------------------------------------
-        float thv;
-        {
-            const float c0 = shfl(th[0], psrc < 0 ? 0 : psrc), c1 = shfl(th[1], psrc < 0 ? 0 : psrc), c2 = shfl(th[2], psrc < 0 ? 0 : psrc);
-            thv = psrc < 0 ? 0.f : (pcomp == 0 ? c0 : (pcomp == 1 ? c1 : c2));
-        }
         float gv = 0.f, lv = 0.f;                // gradient and loss contributions in prior layout
         float lpr = 0.f;
-        if (wpp > 0.f) {
-            float y[TMG];                            // (components beyond M: zero image, +inf constant - never the arg-min)
-#pragma unroll
-            for (int m = 0; m < TMG; ++m) y[m] = sH[m * 64 + lane];
-#pragma unroll 2     // (fully unrolled, the scheduler hoists all 128 LDS reads and spills 500 registers)
-            for (int c = 0; c < 16; ++c) {
-                const float q0 = read_lane(thv, 4 * c), q1 = read_lane(thv, 4 * c + 1), q2 = read_lane(thv, 4 * c + 2),
-                            q3 = read_lane(thv, 4 * c + 3);
-#pragma unroll
-                for (int m = 0; m < TMG; ++m) {
-                    const floatx4 A4 = *reinterpret_cast<const floatx4*>(sA + ((m * 16 + c) * 64 + lane) * 4);
-                    y[m] = fmaf(A4[0], q0, fmaf(A4[1], q1, fmaf(A4[2], q2, fmaf(A4[3], q3, y[m]))));
-                }
-            }
+        if (use_gmm) {
             float best = 3.0e38f;
             int bm = 0;
-            float pcl[TMG];
 #pragma unroll
-            for (int m = 0; m < TMG; ++m) pcl[m] = a.pcl[m];
-#pragma unroll
-            for (int m = 0; m < TMG; ++m) {
-                const float dq = isP ? (thv - sMu[m * 64 + lane]) * (y[m] + sB[m * 64 + lane]) : 0.f;
-                const float ell = 0.5f * wave_sum_fast(dq) + pcl[m];
+            for (int m = 0; m < TMG; ++m) {          // (components beyond M: +inf constant - never the arg-min)
+                const float ell = 0.5f * sQ[wave * TMG + m] + a.pcl[m];
                 const bool lt = ell < best;                      // first minimum wins, as torch.min does
                 best = lt ? ell : best;
                 bm = lt ? m : bm;
             }
-            float yb = y[0];
-#pragma unroll
-            for (int m = 1; m < TMG; ++m) yb = bm == m ? y[m] : yb;
+            const float yb = sY[(wave * TMG + bm) * 64 + lane];
             gv = isP ? wpp * yb : 0.f;
             lpr = wpp * best;
         }
@@ -328,7 +373,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
 hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
     if (a.num_joints > 64 || a.num_shape > 32 || a.prior_dims > 64 || a.num_gauss > TMG) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(TMG * 16 * 64 * 4 + 3 * TMG * 64) * sizeof(float);
+    const size_t lds = (size_t)(TMG * 16 * 64 * 4 + 3 * TMG * 64 + 2 * TW * 64 + TW * TMG * 64 + TW * TMG) * sizeof(float);
     // frames per workgroup: enough to cover the batch with one workgroup per CU (up to 8: two waves per SIMD); small
     // batches get fewer waves per CU, so that every SIMD hosts at most one frame and all CUs work
     int dev = 0, cus = 256;
@@ -348,7 +393,9 @@ hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((k2b_fit_tree_kernel<NS_, CH_>), grid, block, lds, stream, a);                              \
     } while (0)
     const bool chain = a.chain_len > 1;
+    // (capacity 20 = SMPL-X's betas | expression: twelve coefficients of padding cost 36 registers in the 32-wide instantiation)
     if (a.num_shape <= 16) { if (chain) K2B_TREE(16, true); else K2B_TREE(16, false); }
+    else if (a.num_shape <= 20) { if (chain) K2B_TREE(20, true); else K2B_TREE(20, false); }
     else { if (chain) K2B_TREE(32, true); else K2B_TREE(32, false); }
 #undef K2B_TREE
     return hipGetLastError();

@@ -66,6 +66,7 @@ struct FitArgs {
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);
 
 // Kernel arguments of the fused fit for large trees (k2b_fit_tree.hip: 25..64 joints, SMPL-H / SMPL-X).
+typedef _Float16 k2b_half;
 struct FitTreeArgs {
     // model (device), indexed by LANE (DFS pre-order of the kinematic tree)
     const float* dt;            // [64][3]      rest offset from the parent at shape 0 (root: its rest joint)
@@ -75,7 +76,9 @@ struct FitTreeArgs {
     const int* anc;             // [64][4]: lane of the ancestor 1, 2, 4, 8 levels up, or 63 (a non-joint lane: identity)
     int num_joints, num_shape, num_rounds;   // pointer-doubling rounds the targeted joints need: 2^rounds > their depth
     // prior (device): the mixture folded to its first prior_dims <= 64 dimensions (see k2b_fit_tree.hip)
-    const float* pA;            // [M][16][64][4]   A_m[i][4 c + k] at ((m 16 + c) 64 + i) 4 + k
+    const k2b_half* pfrag;      // [8][4 tiles][ks0 hi, ks1 hi, ks0 lo, ks1 lo][64 lanes][8]: the 64 x 64 core of every (scaled) precision
+                                // matrix as v_mfma_f32_16x16x32_f16 A fragments - the image k2b_fit.hip uses (k2b_prior::frag32)
+    float inv_scale[8];         // per component: 1 / (power-of-two scale of its fragments)
     const float *ph, *pb, *pmu; // [M][64]          h = b - A mu, b, mu
     const float* pcl;           // [M]              0.5 c_m - log(nll weight)
     int num_gauss, prior_dims;
@@ -100,7 +103,6 @@ struct FitTreeArgs {
 hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream);
 
 // LBS operands are f16 hi/lo pairs in MFMA fragment order: [k-step][row][16 halfs].
-typedef _Float16 k2b_half;
 constexpr float kPdScale = 256.0f;   // power-of-two scale of the vertex-GEMM B operand (keeps f16 lo terms normal)
 
 // Element (k, row) inside fragment number `frag` of a fragment-ordered operand: a fragment is the
