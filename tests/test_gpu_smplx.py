@@ -285,3 +285,26 @@ def test_smplx_chain_launch_equals_frame_by_frame_launches():
             assert torch.equal(got[k], torch.stack(want[k], dim=1)), (S, T, k)
         if freeze:
             assert torch.equal(got["betas"][:, :, :10], be[:, None, :10].expand(-1, T, -1))
+
+
+def test_smplx_fit_does_not_depend_on_the_workgroup_shape():
+    """The tree kernel runs 1..8 frames (waves) per workgroup by batch size, and the mixture's eight components are spread over
+    those waves (1, 2, 3, 5 or 8 waves: even and uneven shares): the same frame must come out bit for bit whatever batch it
+    rides in, whichever MFMA column it occupies."""
+    from keypoints2body_amd import native, synthetic
+    m, pr = H.native_model_x(), H.native_prior()
+    B = 2048
+    p = synthetic.make_poses_x(B, seed=11)
+    pose = np.concatenate([getattr(p, k) for k, _ in POSE_FIELDS], axis=1)
+    shape = np.concatenate([p.betas, p.expression], axis=1)
+    j, _ = m.lbs(H.cuda(p.global_orient), H.cuda(pose), H.cuda(shape), H.cuda(p.transl), want_vertices=False)
+    j3d = (j[:, :55] + 0.01).contiguous()
+    cfg = native.default_fit_config(); cfg.num_iters = 15; cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
+    z = lambda n, c: torch.zeros(n, c, device="cuda")
+    run = lambda n: native.fit_world(m, pr, cfg, list(range(55)), j3d[:n].contiguous(), None, z(n, 3), z(n, 162), z(n, 20),
+                                     j3d[:n, 0].contiguous())
+    ref = run(B)                                   # 8 waves per workgroup
+    for n in (1, 300, 700, 1200):                  # 1, 2, 3 and 5 waves per workgroup on a 256-CU device
+        out = run(n)
+        for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+            assert torch.equal(out[k], ref[k][:n]), (n, k)
