@@ -252,13 +252,13 @@ def main():
             init = fitter.packed_init(init)
         fit_ev, lbs_ev = [], []
 
-        def step(record=False):
+        def step(record=False, comm=True):
             e0, e1, e2 = ev(), ev(), ev()
             e0.record()
             out = fitter.fit_params(cfg, j3d, init, list(range(K)))
             e1.record()
             # the parameter exchange is enqueued behind the fit and runs on RCCL's stream under the LBS launches
-            gathered, work = gather_fit_outputs(out, dist, pad_to=per, async_op=True) if dist is not None else (None, None)
+            gathered, work = gather_fit_outputs(out, dist, pad_to=per, async_op=True) if (dist is not None and comm) else (None, None)
             joints, verts = fitter.final_forward(out)
             e2.record()
             if work is not None:
@@ -272,10 +272,11 @@ def main():
         # 1024-frame run with only W = 30 warm-up steps = 9 ms of work measured 0.391 ms/step, the same steps behind
         # 0.16 s of other work 0.313).  So the device is kept busy with this very step for PREWARM_S seconds first - set-up,
         # like building the problem, not part of the W warm-up steps or the K timed ones; `config.prewarm_s` states it.
+        # (no collective in it: the number of pre-warm steps is time-based and differs between ranks)
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < PREWARM_S:
             for _ in range(10):
-                step()
+                step(comm=False)
             torch.cuda.synchronize()
         for _ in range(warmup):
             step()
