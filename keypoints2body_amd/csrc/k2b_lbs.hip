@@ -443,9 +443,6 @@ constexpr int kTileSlotBytes = 64 * 1024;
 #ifndef K2B_TILE_CHUNK
 #define K2B_TILE_CHUNK 8
 #endif
-#ifndef K2B_TILE_TOUCH
-#define K2B_TILE_TOUCH 0
-#endif
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -540,10 +537,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     // re-materialisation, whose lgkmcnt traffic forces full drains of the LDS reads)
     unsigned vpoff = 0;
     const unsigned vstride = lane < 4 ? 2u * ftiles * kFragHalfs : 2u * 3u * vtiles * kFragHalfs;   // per 32-deep k-step
-    int touched = 0;              // L2 touches issued behind the fills of the last slice (they may stay in flight)
-    int tsink = 0;                // their (never used) destination
     auto issue = [&]() {
-        touched = 0;
         if (!lw.valid) return;
 #if K2B_TILE_DIAG == 2
         if (lq > 0) { ++lq; if (++ls == spt) { ls = 0; lw.next(); } return; }
@@ -566,25 +560,6 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 __builtin_amdgcn_global_load_lds(src + lane8, slot + (lwv + 4 * i) * 1024, 16, 0, 0);
             }
             vpoff += vstride;
-#if K2B_TILE_TOUCH
-            // L2 warm-up of the k-step AFTER the one just requested: one dword per 128-byte line of this wave's 16 pieces
-            // (128 lines), results never used.  LDS-DMA requests of a wave complete in order, so one L2 miss holds up every
-            // piece behind it: with ~20 % of the lines coming from beyond L2 the fill stream ran at the Infinity-Cache
-            // rate (27 GB/s per CU).  The touches fetch exactly those lines one slice earlier, at no LDS cost.
-            if (ls + 1 < KX) {
-                // scalar base + 32-bit lane offset: X pieces 0-3 (32 lines, both half-waves the same), Pd pieces 4-11, 12-15
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int pi = j == 0 ? ((lane >> 3) & 3) : j == 1 ? 4 + (lane >> 3) : 12 + ((lane >> 3) & 3);
-                    const unsigned o = ((unsigned)__shfl((int)vpoff, pi) + (lane & 7) * 64) * 2;     // bytes
-                    const k2b_half* sb = j == 0 ? xbase : pbase;
-                    // the destination stays reserved for the whole kernel ("+v" on a variable that lives across the tile
-                    // loop): the load returns long after the statement, into whatever the register would otherwise hold
-                    asm volatile("global_load_dword %0, %1, %2" : "+v"(tsink) : "v"(o), "s"(sb) : "memory");
-                }
-                touched = 3;
-            }
-#endif
         } else {
             const int tsl = ls - KX, u = tsl / NTS, ts = tsl - u * NTS;
             unsigned fo[2];       // the u-th 16-frame tile of either wave pair
@@ -665,9 +640,8 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
         stored = pend_valid;
         if (pend_valid) { emit_stores(pend, pend_f, pend_vg); pend_valid = false; }
     };
-    auto loader_wait = [&]() {    // the fills have landed; the L2 touches and the eight stores behind them may fly on
-        if (stored) { if (touched) wait_vmcnt<11>(); else wait_vmcnt<8>(); }
-        else { if (touched) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
+    auto loader_wait = [&]() {    // the fills have landed; the eight stores behind them may fly on
+        if (stored) wait_vmcnt<8>(); else wait_vmcnt<0>();
     };
 
     while (cw.valid) {
@@ -845,7 +819,6 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     }
     if (loader && pend_valid) emit_stores(pend, pend_f, pend_vg);
     wait_vmcnt<0>();
-    asm volatile("" ::"v"(tsink));
 #if K2B_TILE_DIAG == 6
     if (blockIdx.x == 0 || blockIdx.x == 77) {
         wg_barrier();
