@@ -19,7 +19,7 @@ the reference for B = 1 and deliberately differs (independent frames) for B > 1.
 
 Differences, all deliberate and documented in DESIGN.md:
 
-* SMPL-X (55-joint models, ``SMPLXData``): hands, jaw, eyes and expression join the optimiser exactly as in the
+* SMPL-H (52-joint models, ``SMPLHData``: both hands) and SMPL-X (55-joint models, ``SMPLXData``): hands, jaw, eyes and expression join the optimiser exactly as in the
   reference (``world_space.py:126-151,215-229``), fitted by the tree kernel (``csrc/k2b_fit_tree.hip``) over one packed
   pose / shape vector.  The reference hands SMPL-X's 63-D body pose to its 69-D mixture, which raises (SURVEY.md N3);
   here the mixture is evaluated at ``[body_pose | 0 x 6]``, and hands are full axis-angle poses (``use_pca=False``).
@@ -68,10 +68,10 @@ class WorldSpaceFitter:
                  joints_category="SMPL24", device=None, pose_prior_num_gaussians=8,
                  pose_prior: Optional[MaxMixturePrior] = None):
         self.smpl: BodyModel = as_body_model(smpl_model, device=device)
-        if self.smpl.num_joints not in (24, 55):
+        if self.smpl.num_joints not in (24, 52, 55):
             raise NotImplementedError(
                 f"a body model with {self.smpl.num_joints} joints: the fit kernels are built for the 24-joint SMPL tree "
-                "(SMPL-H / SMPL-X parameter sets ride on it unfitted) and the 55-joint SMPL-X tree")
+                "(SMPL-H / SMPL-X parameter sets ride on it unfitted), the 52-joint SMPL-H and the 55-joint SMPL-X tree")
         self.device = self.smpl.device
         self.step_size = step_size
         self.num_iters_first = num_iters_first
@@ -111,7 +111,7 @@ class WorldSpaceFitter:
             raise ValueError(f"j3d must be (B,K,3), got {tuple(j3d.shape)}")
         J = self.smpl.num_joints
         B = j3d.shape[0]
-        smplx = self.smpl.model_type == "smplx"
+        smplx = self.smpl.packed                         # 52- / 55-joint trees (SMPL-H / SMPL-X)
         go = self._dev(init_params.global_orient, 3)
         if smplx:                                        # one pose vector of all non-root joints, one of all shape coefficients
             get = lambda name: getattr(init_params, name, None)
@@ -163,7 +163,7 @@ class WorldSpaceFitter:
         """
         go, bp, be, tr, model_idx, tgt, conf = self._prepare(init_params, j3d, conf_3d, target_model_indices, per_frame_conf)
         J = self.smpl.num_joints
-        smplx = self.smpl.model_type == "smplx"
+        smplx = self.smpl.packed
         cfg = self._config(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
                            per_frame_conf and conf is not None and conf.dim() == 2)
         if smplx:
@@ -201,7 +201,7 @@ class WorldSpaceFitter:
                                                              num_init=1)
         cfg = self._config(0, joint_loss_weight, pose_preserve_weight, freeze_betas, per_frame)
         cfg.pose_preserve_weight = float(pose_preserve_weight)      # frames >= 1 (frame 0 has no preserve term)
-        if self.smpl.model_type == "smplx":
+        if self.smpl.packed:
             cfg.prior_pose_dims, cfg.num_betas_prior = 3 * self.smpl.NUM_BODY_JOINTS, self.smpl.num_betas
         T = tgt.shape[0]
         out = native.fit_sequence(self.smpl.native, self.pose_prior.native, cfg, int(self.num_iters_followup), model_idx,
@@ -256,7 +256,7 @@ class WorldSpaceFitter:
             beta = be[sl].clone()
             # (SMPL-X: the packed shape vector = betas | expression always joins the optimiser; with frozen betas their part of
             #  the gradient is zero (``num_betas_prior``), which leaves them - and L-BFGS's inner products - untouched)
-            shape_in_optimiser = not freeze_betas or self.smpl.model_type == "smplx"
+            shape_in_optimiser = not freeze_betas or self.smpl.packed
             if shape_in_optimiser:
                 beta.requires_grad_(True)
                 p.append(beta)                         # parameter order of world_space.py:215-229
@@ -303,6 +303,10 @@ class WorldSpaceFitter:
         frames of a batched result (hand / face fields a 24-joint fit does not touch are carried from `init_params`)."""
         if rows is not None:
             out = {k: v[rows] for k, v in out.items() if k != "loss"}
+        if self.smpl.model_type == "smplh" and self.smpl.packed:
+            u = self.smpl.unpack(out["body_pose"], out["betas"])
+            return SMPLHData(betas=u["betas"], global_orient=out["global_orient"], body_pose=u["body_pose"], transl=out["transl"],
+                             left_hand_pose=u["left_hand_pose"], right_hand_pose=u["right_hand_pose"])
         if self.smpl.model_type == "smplx":
             u = self.smpl.unpack(out["body_pose"], out["betas"])
             fitted = SMPLXData(betas=u["betas"], global_orient=out["global_orient"], body_pose=u["body_pose"],

@@ -22,14 +22,16 @@ from .. import native, synthetic
 # smplx SMPL-X full pose behind the root: body 63 | jaw | left eye | right eye | left hand 45 | right hand 45 (joints 1..54)
 SMPLX_POSE_FIELDS = (("body_pose", 63), ("jaw_pose", 3), ("leye_pose", 3), ("reye_pose", 3), ("left_hand_pose", 45),
                      ("right_hand_pose", 45))
+SMPLH_POSE_FIELDS = (("body_pose", 63), ("left_hand_pose", 45), ("right_hand_pose", 45))
 
 
 class BodyModel:
     """SMPL-family model on one MI355X.  No CPU path: construction needs a HIP device.
 
-    55-joint models are SMPL-X (``model_type == "smplx"``): the kernels see ONE pose vector of all non-root joints
-    (162 values) and ONE vector of shape coefficients (betas | expression); ``pack_pose`` / ``pack_shape`` /
-    ``unpack`` translate from and to smplx's keyword arguments (hands as full axis-angle poses, ``use_pca=False``)."""
+    55-joint models are SMPL-X (``model_type == "smplx"``), 52-joint models SMPL-H (``"smplh"``): the kernels see ONE pose
+    vector of all non-root joints (162 / 153 values) and ONE vector of shape coefficients (betas | expression);
+    ``pack_pose`` / ``pack_shape`` / ``unpack`` translate from and to smplx's keyword arguments (hands as full axis-angle
+    poses, ``use_pca=False``).  ``packed`` says whether a model takes that route."""
 
     NUM_BODY_JOINTS = 23
     NUM_HAND_JOINTS = 15
@@ -39,9 +41,13 @@ class BodyModel:
         self.native = native.NativeModel(v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents,
                                          extra_vertex_ids, device=device)
         self.device = self.native.device
-        self.model_type = "smplx" if self.native.num_joints == 55 else model_type
+        nj = self.native.num_joints
+        self.model_type = "smplx" if nj == 55 else ("smplh" if nj == 52 else model_type)
+        self.packed = self.model_type in ("smplx", "smplh") and nj in (52, 55)
+        self.pose_fields = SMPLX_POSE_FIELDS if nj == 55 else SMPLH_POSE_FIELDS
         self.num_shape = self.native.num_betas                     # everything the shape blend takes
-        if self.model_type == "smplx":
+        self.num_expression_coeffs = 0
+        if self.packed:
             self.NUM_BODY_JOINTS = 21
             self.num_betas = 10 if self.num_shape > 10 else self.num_shape
             self.num_expression_coeffs = self.num_shape - self.num_betas
@@ -60,6 +66,13 @@ class BodyModel:
                    c.extra_vertex_ids, device=device)
 
     @classmethod
+    def synthetic_h(cls, seed: int = 0, device=None) -> "BodyModel":
+        """SMPL-H-shaped synthetic model (52 joints, V = 6890, 10 betas)."""
+        c = synthetic.make_body_model_h(seed)
+        return cls(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents,
+                   c.extra_vertex_ids, device=device, model_type="smplh")
+
+    @classmethod
     def synthetic_x(cls, seed: int = 0, device=None) -> "BodyModel":
         """SMPL-X-shaped synthetic model (55 joints, V = 10475, 10 betas + 10 expression coefficients)."""
         c = synthetic.make_body_model_x(seed)
@@ -69,11 +82,11 @@ class BodyModel:
     # -- SMPL-X packing ---------------------------------------------------------------------
     def pack_pose(self, B: int, **kw) -> torch.Tensor:
         """(B, 3 (J - 1)) pose of all non-root joints from smplx keyword arguments (missing ones are zero)."""
-        if self.model_type != "smplx":
+        if not self.packed:
             return self._as_dev(kw.get("body_pose"), 3 * (self.num_joints - 1)) if kw.get("body_pose") is not None \
                 else torch.zeros((B, 3 * (self.num_joints - 1)), dtype=torch.float32, device=self.device)
         parts = []
-        for name, cols in SMPLX_POSE_FIELDS:
+        for name, cols in self.pose_fields:
             x = kw.get(name)
             t = self._as_dev(x, cols) if x is not None else torch.zeros((B, cols), dtype=torch.float32, device=self.device)
             parts.append(t.expand(B, -1) if t.shape[0] != B else t)
@@ -81,7 +94,7 @@ class BodyModel:
 
     def pack_shape(self, B: int, betas=None, expression=None) -> torch.Tensor:
         z = lambda c: torch.zeros((B, c), dtype=torch.float32, device=self.device)
-        if self.model_type != "smplx":
+        if not self.packed:
             return self._as_dev(betas, self.num_shape) if betas is not None else z(self.num_shape)
         be = self._as_dev(betas, self.num_betas) if betas is not None else z(self.num_betas)
         ex = self._as_dev(expression, self.num_expression_coeffs) if expression is not None else z(self.num_expression_coeffs)
@@ -90,10 +103,10 @@ class BodyModel:
 
     def unpack(self, pose: torch.Tensor, shape: torch.Tensor) -> dict:
         """Inverse of pack_pose / pack_shape: smplx field name -> tensor."""
-        if self.model_type != "smplx":
+        if not self.packed:
             return {"body_pose": pose, "betas": shape}
         out, o = {}, 0
-        for name, cols in SMPLX_POSE_FIELDS:
+        for name, cols in self.pose_fields:
             out[name] = pose[:, o:o + cols].contiguous()
             o += cols
         out["betas"] = shape[:, :self.num_betas].contiguous()
@@ -138,7 +151,7 @@ class BodyModel:
         B = max((int(torch.as_tensor(x).reshape(-1, torch.as_tensor(x).shape[-1]).shape[0]) for x in given), default=1)
         zeros = lambda c: torch.zeros((B, c), dtype=torch.float32, device=self.device)
         go = self._as_dev(global_orient, 3) if global_orient is not None else zeros(3)
-        if self.model_type == "smplx":
+        if self.packed:
             bp = self.pack_pose(B, body_pose=body_pose, **{k: v for k, v in extra.items() if k != "expression"})
             be = self.pack_shape(B, betas, extra["expression"])
         else:

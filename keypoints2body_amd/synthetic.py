@@ -70,6 +70,22 @@ SMPLX_PARENTS = np.array(
 )
 
 
+# SMPL-H kinematic tree (52 joints, smplx numbering): the SMPL-X tree without jaw and eyes - 0-21 body, 22-36 left hand,
+# 37-51 right hand.
+SMPLH_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+     20, 22, 23, 20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35,
+     21, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50],
+    dtype=np.int32,
+)
+
+
+def _smplh_rest_joints() -> np.ndarray:
+    """The 55-joint T-pose skeleton below without its jaw and eye joints."""
+    r = _smplx_rest_joints()
+    return np.concatenate([r[:22], r[25:]], axis=0)
+
+
 def _smplx_rest_joints() -> np.ndarray:
     """Plausible T-pose skeleton of the 55-joint tree: the SMPL body joints 0-21, jaw and eyes on the head, five
     three-joint fingers fanning out of either wrist (hand-written, not a licensed template)."""
@@ -182,6 +198,12 @@ def make_body_model_x(seed: int = 0, num_vertices: int = 10475, num_shape: int =
     """SMPL-X-shaped synthetic model: V = 10475, 55 joints on the SMPL-X tree, 20 shape coefficients (10 betas | 10
     expression coefficients, concatenated as smplx does), 486 pose-corrective rows, 55 + 72 = 127 output joints."""
     return make_body_model(seed, num_vertices, num_shape, parents=SMPLX_PARENTS.copy(), rest=_smplx_rest_joints(),
+                           num_extra=num_extra)
+
+
+def make_body_model_h(seed: int = 0, num_vertices: int = 6890, num_betas: int = 10, num_extra: int = 21) -> SyntheticBodyModel:
+    """SMPL-H-shaped synthetic model: V = 6890, 52 joints (body + two 15-joint hands), 10 betas, 459 pose-corrective rows."""
+    return make_body_model(seed, num_vertices, num_betas, parents=SMPLH_PARENTS.copy(), rest=_smplh_rest_joints(),
                            num_extra=num_extra)
 
 
@@ -318,6 +340,25 @@ def make_poses_x(num_frames: int, seed: int = 0) -> SyntheticPosesX:
         global_orient=f(40, 3, 0.3), body_pose=f(41, 63, 0.2), jaw_pose=f(42, 3, 0.1), leye_pose=f(43, 3, 0.05),
         reye_pose=f(44, 3, 0.05), left_hand_pose=f(45, 45, 0.15), right_hand_pose=f(46, 45, 0.15),
         betas=f(47, 10, 0.5), expression=f(48, 10, 0.5), transl=f(49, 3, 1.0))
+
+
+@dataclass
+class SyntheticPosesH:
+    """Ground-truth SMPL-H parameters (smplx field names; hands as full axis-angle poses, use_pca=False)."""
+
+    global_orient: np.ndarray    # (T,3)
+    body_pose: np.ndarray        # (T,63)
+    left_hand_pose: np.ndarray   # (T,45)
+    right_hand_pose: np.ndarray  # (T,45)
+    betas: np.ndarray            # (T,10)
+    transl: np.ndarray           # (T,3)
+
+
+def make_poses_h(num_frames: int, seed: int = 0) -> SyntheticPosesH:
+    T = num_frames
+    f = lambda stream, cols, scale: (scale * normalish(stream, (T, cols), seed)).astype(np.float32)
+    return SyntheticPosesH(global_orient=f(50, 3, 0.3), body_pose=f(51, 63, 0.2), left_hand_pose=f(52, 45, 0.15),
+                           right_hand_pose=f(53, 45, 0.15), betas=f(54, 10, 0.5), transl=f(55, 3, 1.0))
 
 
 def target_noise(num_frames: int, num_joints: int, seed: int = 0, scale: float = 0.005) -> np.ndarray:

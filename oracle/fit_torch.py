@@ -185,16 +185,20 @@ SMPLX_FIELDS = ("global_orient", "body_pose", "transl", "left_hand_pose", "right
                 "leye_pose", "reye_pose", "betas")      # the optimiser's parameter list, world_space.py:215-229
 
 
+SMPLH_FIELDS = ("global_orient", "body_pose", "transl", "left_hand_pose", "right_hand_pose", "betas")
+
+
 def fit_world_adam_smplx(model, prior: GMMPrior, params: dict, j3d, conf=None, *, num_iters: int, lr: float = 1e-2,
                          seq_ind: int = 0, model_idx: Optional[Sequence[int]] = None, weights: Optional[FitWeights] = None,
-                         freeze_betas: bool = False, trace_iters: Sequence[int] = ()):
+                         freeze_betas: bool = False, trace_iters: Sequence[int] = (), fields: Sequence[str] = ()):
     """Adam branch of ``WorldSpaceFitter.fit_frame`` for ``SMPLXData`` inputs (world_space.py:126-151: hands, expression,
     jaw and eyes join the optimiser; 173-192: they are passed to the model; 202-212: the loss sees ``body_pose`` (63-D,
     prior zero-padded to the mixture's 69 dimensions - see ``GMMPrior.per_component``), ``betas`` (not the expression)
     and the model joints).  ``params``: dict of (B, .) tensors with the keys of ``SMPLX_FIELDS``.
     Returns (dict of fitted tensors, per-frame loss of the last iteration before its step, joints, vertices, trace)."""
     w = weights or FitWeights()
-    p = {k: params[k].clone().detach().requires_grad_(True) for k in SMPLX_FIELDS}
+    # (``fields=SMPLH_FIELDS``: the same branch for ``SMPLHData`` - both hands join the optimiser, no face / expression)
+    p = {k: params[k].clone().detach().requires_grad_(True) for k in (fields or SMPLX_FIELDS)}
     p["betas"].requires_grad = not freeze_betas
     preserve = p["body_pose"].clone().detach()
     K = j3d.shape[1]

@@ -168,6 +168,33 @@ class TorchSMPLX(TorchSMPL):
                                body_pose=parts[1], full_pose=full_pose if return_full_pose else None)
 
 
+class TorchSMPLH(TorchSMPL):
+    """SMPL-H duck type (smplx ``SMPLH.forward`` with ``use_pca=False``): 52 joints, full pose = [global_orient |
+    body_pose 63 | left_hand_pose 45 | right_hand_pose 45], 10 betas.  PARITY UNPINNED at the smplx boundary like ``TorchSMPL``."""
+
+    NUM_BODY_JOINTS = 21
+    NUM_HAND_JOINTS = 15
+
+    def __init__(self, consts, dtype=torch.float32):
+        super().__init__(consts, dtype)
+        self.num_betas = int(self.shapedirs.shape[2])
+
+    def forward(self, global_orient=None, body_pose=None, betas=None, transl=None, left_hand_pose=None, right_hand_pose=None,
+                return_full_pose=False, return_verts=True, **_unused):
+        given = [x for x in (global_orient, body_pose, betas, left_hand_pose) if x is not None]
+        B = max(x.shape[0] for x in given)
+        dev, dt = self.v_template.device, self.dtype
+        z = lambda x, c: torch.zeros(B, c, dtype=dt, device=dev) if x is None else x
+        parts = [z(global_orient, 3), z(body_pose, 63), z(left_hand_pose, 45), z(right_hand_pose, 45)]
+        if parts[1].shape[1] != 63:
+            raise ValueError(f"SMPL-H body_pose must be (B,63), got {tuple(parts[1].shape)}")
+        full_pose = torch.cat(parts, dim=1)
+        shape = z(betas, self.num_betas)
+        joints, verts = self._lbs(full_pose, shape, transl)
+        return SimpleNamespace(vertices=verts, joints=joints, betas=shape, global_orient=parts[0], body_pose=parts[1],
+                               full_pose=full_pose if return_full_pose else None)
+
+
 # --------------------------------------------------------------------------
 # float64 numpy twin: an independent, loop-style restatement used to check the
 # torch module above (different code path: explicit per-joint loops).

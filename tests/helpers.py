@@ -39,6 +39,28 @@ def oracle_model_x(seed: int = 0, double: bool = False):
     return TorchSMPLX(body_consts_x(seed), dtype=torch.float64 if double else torch.float32)
 
 
+def body_consts_h(seed: int = 0):
+    return synthetic.make_body_model_h(seed)
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_model_h(seed: int = 0):
+    from oracle.smpl_torch import TorchSMPLH
+    return TorchSMPLH(body_consts_h(seed))
+
+
+@functools.lru_cache(maxsize=None)
+def native_model_h(seed: int = 0):
+    from keypoints2body_amd.native import NativeModel
+    c = body_consts_h(seed)
+    return NativeModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents,
+                       c.extra_vertex_ids)
+
+
+def load_smplh_case(name: str):
+    return dict(np.load(GOLDEN / f"smplh_fit_{name}.npz"))
+
+
 def load_smplx_case(name: str):
     return dict(np.load(GOLDEN / f"smplx_fit_{name}.npz"))
 

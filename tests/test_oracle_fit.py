@@ -134,3 +134,27 @@ def test_oracle_reproduces_reference_smplx_fit(case):
     if int(d["freeze_betas"]):
         assert np.array_equal(params["betas"].numpy(), d["init_betas"])
         assert np.abs(params["expression"].numpy() - d["init_expression"]).max() > 1e-4    # the expression stays free
+
+
+@pytest.mark.parametrize("case", ("all52_zero_init", "all52_followup_frozen"))
+def test_oracle_reproduces_reference_smplh_fit(case):
+    """SMPL-H goldens (oracle/gen_golden_smplh.py: the real reference fitter with SMPLHData, 52-joint tree, both hands in the
+    optimiser) against the oracle's restatement, at every recorded iteration."""
+    from oracle.fit_torch import SMPLH_FIELDS, fit_world_adam_smplx
+    d = H.load_smplh_case(case)
+    t = lambda k: torch.tensor(d[k])
+    idx = [int(i) for i in d["target_model_indices"]]
+    params, loss, joints, verts, trace = fit_world_adam_smplx(
+        H.oracle_model_h(), H.oracle_prior(), {k: t("init_" + k) for k in SMPLH_FIELDS}, t("j3d"), t("conf"),
+        num_iters=int(d["num_iters"]), seq_ind=int(d["seq_ind"]), model_idx=idx, freeze_betas=bool(int(d["freeze_betas"])),
+        trace_iters=tuple(int(i) for i in d["trace_iters"]), fields=SMPLH_FIELDS)
+    for ti, it in enumerate(d["trace_iters"]):
+        for k in SMPLH_FIELDS:
+            assert np.abs(trace[int(it)][k].numpy() - d["trace_" + k][ti]).max() < TOL, (case, int(it), k)
+    for k in SMPLH_FIELDS:
+        assert np.abs(params[k].numpy() - d["out_" + k]).max() < TOL, (case, k)
+    assert np.abs(joints.numpy() - d["out_joints"]).max() < TOL
+    assert np.abs(verts[:, torch.as_tensor(d["sampled_vertex_ids"])].numpy() - d["out_verts_sampled"]).max() < TOL
+    np.testing.assert_allclose(loss.numpy(), d["iter_losses"][:, -1], rtol=1e-5)
+    if int(d["freeze_betas"]):
+        assert np.array_equal(params["betas"].numpy(), d["init_betas"])
