@@ -166,27 +166,31 @@ class CameraSpaceFitter:
         NB = start["betas"].shape[1]
         preserve = start["body_pose"].clone()                     # camera_space.py:136
         rows = {k: [] for k in ("global_orient", "body_pose", "betas", "transl")}
+        # (the optimiser's own arithmetic runs on HOST tensors, as in the reference: see WorldSpaceFitter._fit_lbfgs)
+        dev = self.device
+        order = ("global_orient", "body_pose", "betas", "transl")
         for f in range(B):
             sl = slice(f, f + 1)
-            p = {k: start[k][sl].clone() for k in rows}
+            p = {k: start[k][sl].detach().to("cpu").clone() for k in rows}
             cf = conf[sl].contiguous() if (conf is not None and conf.dim() == 2) else conf
+            pres_f, cam_f = preserve[sl].contiguous(), cam_t0[sl].contiguous()
 
             def run(cfg, idx, tgt, cfv, opt_keys):
                 params = [p[k].requires_grad_(True) for k in opt_keys]
                 cols = {"global_orient": slice(0, 3), "body_pose": slice(3, 3 + D), "betas": slice(3 + D, 3 + D + NB),
                         "transl": slice(3 + D + NB, 3 + D + NB + 3)}
+                tgt_f = tgt[sl].contiguous()
 
                 def closure():
                     with torch.no_grad():
-                        cur = (p["global_orient"].detach().contiguous(), p["body_pose"].detach().contiguous(),
-                               p["betas"].detach().contiguous(), p["transl"].detach().contiguous())
-                        kw = dict(preserve_pose=preserve[sl].contiguous(), want_grad=True,
-                                  transl_prior_target=cam_t0[sl].contiguous())
-                        r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt[sl].contiguous(), cfv,
-                                             *cur, **kw)
+                        flat = torch.cat([p[k].detach() for k in order], dim=1).to(dev)
+                        cur = tuple(flat[:, cols[k]].contiguous() for k in order)
+                        r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt_f, cfv, *cur,
+                                             preserve_pose=pres_f, want_grad=True, transl_prior_target=cam_f)
+                        back = torch.cat((r["grad"], r["loss"][:, None]), dim=1).cpu()
                     for k in opt_keys:
-                        p[k].grad = r["grad"][:, cols[k]].clone()
-                    return r["loss"].sum()
+                        p[k].grad = back[:, cols[k]].clone()
+                    return back[:, -1].sum()
 
                 torch.optim.LBFGS(params, max_iter=max_iter, lr=lr, line_search_fn="strong_wolfe").step(closure)
                 for k in opt_keys:
@@ -195,5 +199,5 @@ class CameraSpaceFitter:
             run(cfg1, idx1, tgt1, None, ["global_orient", "transl"])                       # camera_space.py:142
             run(cfg2, idx2, tgt2, cf, ["body_pose"] + (["betas"] if fit_betas else []) + ["global_orient", "transl"])  # :219-224
             for k in rows:
-                rows[k].append(p[k].detach())
+                rows[k].append(p[k].detach().to(dev))
         return {k: torch.cat(v, dim=0).contiguous() for k, v in rows.items()}

@@ -11,7 +11,8 @@ one ``k2b_lbs`` call for the final vertices/joints (``world_space.py:258-278``).
 ``use_lbfgs=True`` (the reference's default, ``world_space.py:231-247``) keeps
 ``torch.optim.LBFGS`` (strong Wolfe) as the outer algorithm, exactly as the reference does, but its
 closure no longer builds an autograd graph: loss and gradient of every evaluation come from an
-evaluate-only launch of the same kernel (``step_size = 0``, ``grad_out``).  L-BFGS couples all
+evaluate-only launch of the same kernel (``step_size = 0``, ``grad_out``); the optimiser's own vectors live on the
+host (one upload of the parameters and one download of [gradient | loss] per closure call).  L-BFGS couples all
 parameters it is given: the reference hands ONE optimiser the parameters of the whole batch, so for
 B > 1 its frames share a line search (a batch is then NOT B independent fits); the API only ever
 calls it with B = 1 (``api/sequence.py:215``).  This class runs one L-BFGS per frame, which equals
@@ -249,11 +250,16 @@ class WorldSpaceFitter:
         NB = be.shape[1]
         preserve = bp.clone()                          # world_space.py:159
         outs = {k: [] for k in ("global_orient", "body_pose", "betas", "transl", "loss")}
+        # The optimiser's own arithmetic (two-loop recursion, strong-Wolfe bookkeeping: hundreds of tiny tensor operations per
+        # iteration) runs on HOST tensors, as it does in the reference (whose default device is the CPU): on device tensors every
+        # one of them is a kernel launch, and a 30-iteration fit took 21 ms of which the evaluate-only launches were 0.3 ms.
+        # Per closure call: one upload of the packed parameters, one launch, one download of [gradient | loss].
+        dev = self.device
+        host = lambda t: t.detach().to("cpu").clone()
         for f in range(B):
             sl = slice(f, f + 1)
-            p = [go[sl].clone().requires_grad_(True), bp[sl].clone().requires_grad_(True),
-                 tr[sl].clone().requires_grad_(True)]
-            beta = be[sl].clone()
+            p = [host(go[sl]).requires_grad_(True), host(bp[sl]).requires_grad_(True), host(tr[sl]).requires_grad_(True)]
+            beta = host(be[sl])
             # (SMPL-X: the packed shape vector = betas | expression always joins the optimiser; with frozen betas their part of
             #  the gradient is zero (``num_betas_prior``), which leaves them - and L-BFGS's inner products - untouched)
             shape_in_optimiser = not freeze_betas or self.smpl.packed
@@ -262,28 +268,33 @@ class WorldSpaceFitter:
                 p.append(beta)                         # parameter order of world_space.py:215-229
             cf = conf[sl].contiguous() if (conf is not None and conf.dim() == 2) else conf
             pres = preserve[sl].contiguous()
+            tgt_f = tgt[sl].contiguous()
 
             def evaluate(want_grad):
                 with torch.no_grad():
-                    cur = (p[0].detach().contiguous(), p[1].detach().contiguous(), beta.detach().contiguous(),
-                           p[2].detach().contiguous())
-                    return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt[sl].contiguous(),
-                                            cf, *cur, preserve_pose=pres, want_grad=want_grad)
+                    flat = torch.cat((p[0].detach(), p[1].detach(), beta.detach(), p[2].detach()), dim=1).to(dev)
+                    cur = (flat[:, 0:3].contiguous(), flat[:, 3:3 + D].contiguous(), flat[:, 3 + D:3 + D + NB].contiguous(),
+                           flat[:, 3 + D + NB:].contiguous())
+                    r = native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt_f, cf, *cur,
+                                         preserve_pose=pres, want_grad=want_grad)
+                    if not want_grad:
+                        return r["loss"], None
+                    back = torch.cat((r["grad"], r["loss"][:, None]), dim=1).cpu()
+                    return back[:, -1], back[:, :-1]
 
             def closure():
-                r = evaluate(True)
-                g = r["grad"]
+                loss, g = evaluate(True)
                 p[0].grad = g[:, 0:3].clone()
                 p[1].grad = g[:, 3:3 + D].clone()
                 p[2].grad = g[:, 3 + D + NB:].clone()
                 if shape_in_optimiser:
                     beta.grad = g[:, 3 + D:3 + D + NB].clone()
-                return r["loss"].sum()
+                return loss.sum()
 
             torch.optim.LBFGS(p, max_iter=max_iter, lr=float(self.step_size), line_search_fn="strong_wolfe").step(closure)
-            final = evaluate(False)                    # world_space.py:245-246
-            outs["global_orient"].append(p[0].detach()); outs["body_pose"].append(p[1].detach())
-            outs["transl"].append(p[2].detach()); outs["betas"].append(beta.detach()); outs["loss"].append(final["loss"])
+            final_loss, _ = evaluate(False)            # world_space.py:245-246
+            outs["global_orient"].append(p[0].detach().to(dev)); outs["body_pose"].append(p[1].detach().to(dev))
+            outs["transl"].append(p[2].detach().to(dev)); outs["betas"].append(beta.detach().to(dev)); outs["loss"].append(final_loss)
         return {k: torch.cat(v, dim=0).contiguous() for k, v in outs.items()}
 
     def fit_frame(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
