@@ -9,6 +9,7 @@
 #include <mutex>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/k2b.h"
@@ -596,6 +597,12 @@ int folded_prior(k2b_prior* p, int Dv, k2b_prior::Folded* out) {
     return K2B_OK;
 }
 
+extern "C++" {
+template <class Args, class Launch>
+int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, Args a, const float* tr_prior_src, int frozen_shape,
+                            const std::vector<int>& vsel, const std::vector<int>& vcol, hipStream_t stream, Launch launch_eval);
+}
+
 // large trees (SMPL-H / SMPL-X), or a prior over a prefix of the body pose: k2b_fit_tree.hip
 int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int prior_dims, int32_t B, int32_t K,
              const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in, const float* bp_in,
@@ -618,11 +625,18 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
         return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: NULL parameter / target buffer (init transl is required, world_space.py:118-119)");
     k2b::FitTreeArgs a{};
     for (int l = 0; l < 64; ++l) a.lane_target[l] = -1;
-    int maxd = 0;
+    int maxd = 0, num_kinematic = 0;
+    std::vector<int> vsel, vcol;             // vertex-selected joints: index into the model's extra joints, target column
     for (int k = 0; k < K; ++k) {
         const int j = model_joint_index[k];
         if (j < 0 || j >= J + model->E) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model_joint_index[%d]=%d out of range", k, j);
-        if (j >= J) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: model_joint_index[%d]=%d is a vertex-selected joint; the tree kernel fits kinematic joints only", k, j);
+        if (j >= J) {                        // vertex-selected joint: its term comes from k2b_vertex_term_kernel
+            if ((int)vsel.size() >= 32) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: more than 32 vertex-selected joints among the targets");
+            vsel.push_back(j - J);
+            vcol.push_back(k);
+            continue;
+        }
+        ++num_kinematic;
         const int l = model->tt_lane_of[j];
         if (a.lane_target[l] >= 0) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: joint %d is targeted twice", j);
         a.lane_target[l] = k;
@@ -681,6 +695,14 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
     a.opt_mask = cfg->optimize_mask & 15;
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;
+    if (!vsel.empty()) {
+        if (num_kinematic == 0)
+            return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: at least one kinematic joint (model index < %d) must be among the targets", J);
+        if (chain_len > 1)
+            return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_sequence: vertex-selected joints are not built into the chain (fit frame by frame)");
+        return fit_world_vertex_joints(model, cfg, a, nullptr, cfg->freeze_betas ? a.num_betas_prior : 0, vsel, vcol, (hipStream_t)stream,
+                                       [&](const k2b::FitTreeArgs& e) { return k2b::launch_fit_tree(e, (hipStream_t)stream); });
+    }
     HIP_TRY(k2b::launch_fit_tree(a, (hipStream_t)stream));
     return K2B_OK;
 }
@@ -691,8 +713,10 @@ namespace {
 // fits kinematic joints only, so every iteration is two launches queued back to back: the fused kernel in evaluate-only
 // mode (kinematic targets + every prior -> loss, gradient) and the vertex-term kernel with its Adam tail (vertex targets,
 // sum of the gradients, the optimiser step in place).  `a` is the fused launch fully set up for the caller's buffers.
-int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, k2b::FitArgs a, const std::vector<int>& vsel,
-                            const std::vector<int>& vcol, hipStream_t stream) {
+extern "C++" {
+template <class Args, class Launch>
+int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, Args a, const float* tr_prior_src, int frozen_shape,
+                            const std::vector<int>& vsel, const std::vector<int>& vcol, hipStream_t stream, Launch launch_eval) {
     const int B = a.num_frames, NB = model->NB, D = 3 * (model->J - 1), P = 3 + D + NB + 3;
     const int iters = cfg->num_iters;
     float2 *coef = nullptr, *coef_eval = nullptr;
@@ -713,7 +737,7 @@ int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, k2b::Fi
 #define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_world: HIP call failed in the vertex-joint path")); } } while (0)
     K2B_TRY_WS(hipMemsetAsync(mbuf, 0, 2 * n_g * sizeof(float), stream));
     K2B_TRY_WS(hipMemcpyAsync(pres, a.preserve ? a.preserve : a.bp_in, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    K2B_TRY_WS(hipMemcpyAsync(trp, a.tr_prior, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    K2B_TRY_WS(hipMemcpyAsync(trp, tr_prior_src ? tr_prior_src : a.tr_in, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     const struct { const float* src; float* dst; size_t n; } cp[] = {
         {a.go_in, a.go_out, (size_t)B * 3}, {a.bp_in, a.bp_out, (size_t)B * D}, {a.be_in, a.be_out, (size_t)B * NB}, {a.tr_in, a.tr_out, (size_t)B * 3}};
     for (const auto& c : cp)
@@ -721,14 +745,16 @@ int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, k2b::Fi
     float* user_grad = a.grad_out;
     float* user_loss = a.loss_out;
     a.go_in = a.go_out; a.bp_in = a.bp_out; a.be_in = a.be_out; a.tr_in = a.tr_out;
-    a.preserve = pres; a.tr_prior = trp;
+    a.preserve = pres;
+    if constexpr (std::is_same<Args, k2b::FitArgs>::value) a.tr_prior = trp;
     a.adam_coef = coef_eval; a.num_iters = 1;
     a.loss_out = lbuf; a.grad_out = gbuf;
 
     k2b::VertexTermArgs v{};
     v.v_template = model->v_template; v.shapedirs = model->shapedirs; v.posedirs = model->posedirs; v.lbs_weights = model->lbs_weights;
     v.j_template = model->j_template; v.j_dirs = model->j_dirs; v.parents = model->parents; v.extra_ids = model->extra_ids;
-    v.num_vertices = model->V; v.num_betas = NB;
+    v.num_vertices = model->V; v.num_betas = NB; v.num_joints = model->J;
+    v.frozen_shape = frozen_shape;
     v.num_frames = B; v.num_sel = (int)vsel.size();
     for (size_t e = 0; e < vsel.size(); ++e) { v.sel[e] = vsel[e]; v.sel_k[e] = vcol[e]; }
     v.num_targets = a.num_targets; v.targets = a.j3d; v.conf = a.conf; v.conf_per_frame = a.conf_per_frame;
@@ -741,7 +767,7 @@ int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, k2b::Fi
     v.one_minus_beta1 = a.one_minus_beta1; v.beta2 = a.beta2; v.one_minus_beta2 = a.one_minus_beta2; v.eps = a.eps;
     v.opt_mask = a.opt_mask;
     for (int it = 0; it < iters; ++it) {
-        K2B_TRY_WS(k2b::launch_fit_world(a, stream));
+        K2B_TRY_WS(launch_eval(a));
         v.adam_coef = coef + it;
         const bool last = it == iters - 1;
         v.loss_out = last ? loss_sink : lbuf;        // (lbuf: read and written by the same lane)
@@ -751,6 +777,7 @@ int fit_world_vertex_joints(k2b_model* model, const k2b_fit_config* cfg, k2b::Fi
 #undef K2B_TRY_WS
     return cleanup(K2B_OK);
 }
+}  // extern "C++"
 }  // namespace
 
 namespace {
@@ -858,7 +885,9 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;
     a.num_cus = device_cus();
-    if (!vsel.empty()) return fit_world_vertex_joints(model, cfg, a, vsel, vcol, (hipStream_t)stream);
+    if (!vsel.empty())
+        return fit_world_vertex_joints(model, cfg, a, a.tr_prior, 0, vsel, vcol, (hipStream_t)stream,
+                                       [&](const k2b::FitArgs& e) { return k2b::launch_fit_world(e, (hipStream_t)stream); });
     HIP_TRY(k2b::launch_fit_world(a, (hipStream_t)stream));
     return K2B_OK;
 }
@@ -984,7 +1013,7 @@ int k2b_vertex_term(const k2b_model* model_c, int32_t B, int32_t E_sel, const in
     if (!m) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: model is NULL");
     if (B < 0 || E_sel < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: negative size");
     if (B == 0 || E_sel == 0) return K2B_OK;
-    if (m->J != k2b::kFitJoints) return fail(K2B_ERR_UNSUPPORTED, "k2b_vertex_term: built for the %d-joint SMPL tree, model has %d", k2b::kFitJoints, m->J);
+    if (m->J > 64 || m->NB > 32) return fail(K2B_ERR_UNSUPPORTED, "k2b_vertex_term: %d joints / %d shape coefficients, at most 64 / 32", m->J, m->NB);
     if (E_sel > 32) return fail(K2B_ERR_UNSUPPORTED, "k2b_vertex_term: %d vertex-selected joints, at most 32 per call", E_sel);
     if (!extra_index || !targets || !go || !bp || !be || !tr || !loss_out || !grad_out)
         return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_vertex_term: NULL buffer");
@@ -995,7 +1024,7 @@ int k2b_vertex_term(const k2b_model* model_c, int32_t B, int32_t E_sel, const in
     k2b::VertexTermArgs a{};
     a.v_template = m->v_template; a.shapedirs = m->shapedirs; a.posedirs = m->posedirs; a.lbs_weights = m->lbs_weights;
     a.j_template = m->j_template; a.j_dirs = m->j_dirs; a.parents = m->parents; a.extra_ids = m->extra_ids;
-    a.num_vertices = m->V; a.num_betas = m->NB;
+    a.num_vertices = m->V; a.num_betas = m->NB; a.num_joints = m->J;
     a.num_frames = B; a.num_sel = E_sel; a.targets = targets; a.conf = conf;
     for (int e = 0; e < E_sel; ++e) { a.sel[e] = extra_index[e]; a.sel_k[e] = e; }
     a.num_targets = E_sel;

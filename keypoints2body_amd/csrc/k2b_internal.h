@@ -182,7 +182,7 @@ struct VertexTermArgs {
     // model (device): smplx tensors as uploaded by k2b_model_create
     const float *v_template, *shapedirs, *posedirs, *lbs_weights, *j_template, *j_dirs;
     const int *parents, *extra_ids;
-    int num_vertices, num_betas;
+    int num_vertices, num_betas, num_joints;
     // call
     int num_frames, num_sel;
     int sel[32];                // index into extra_ids of every fitted vertex joint
@@ -202,6 +202,7 @@ struct VertexTermArgs {
     const float2* adam_coef;            // this step's {lr / (1 - b1^t), sqrt(1 - b2^t)}
     float one_minus_beta1, beta2, one_minus_beta2, eps;
     int opt_mask;
+    int frozen_shape;                   // the first `frozen_shape` shape coefficients take no step (frozen betas beside a free expression)
 };
 hipError_t launch_vertex_term(const VertexTermArgs& a, hipStream_t stream);
 hipError_t launch_adam(float* x, const float* g, float* m, float* v, long long n, float lr_over_bc1, float sqrt_bc2,

@@ -27,7 +27,6 @@ namespace k2b {
 
 namespace {
 
-constexpr int VJ = kFitJoints;          // 24
 constexpr int VE = 32;                  // selected vertices per launch (one lane each)
 
 __device__ __forceinline__ Vec3 axial_of_GRt(const Mat3& G, const Mat3& R) {
@@ -40,14 +39,18 @@ __device__ __forceinline__ Vec3 axial_of_GRt(const Mat3& G, const Mat3& R) {
     return {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
 }
 
+// VJM / NBM: capacity in joints / shape coefficients (24 / 16: SMPL, the arithmetic of round 1 unchanged; 64 / 32: SMPL-H, SMPL-X)
+template <int VJM, int NBM>
 __global__ __launch_bounds__(64) void k2b_vertex_term_kernel(const VertexTermArgs a) {
-    __shared__ float sR[VJ][9], sRg[VJ][9], sp[VJ][3], sJr[VJ][3];
-    __shared__ float sX[9 * (VJ - 1) + 1];
+    constexpr int kMaxBetas = NBM;          // (shadows the 24-joint kernel's constant inside this kernel)
+    const int VJ = a.num_joints;
+    __shared__ float sR[VJM][9], sRg[VJM][9], sp[VJM][3], sJr[VJM][3];
+    __shared__ float sX[9 * (VJM - 1) + 1];
     __shared__ float svp[VE][3], sg[VE][3], sgvp[VE][3];
-    __shared__ float sF[VJ][3], sM[VJ][3];
-    __shared__ float sGX[9 * (VJ - 1) + 1];
-    __shared__ float sGrad[3 + 3 * (VJ - 1) + kMaxBetas + 3];
-    __shared__ int spar[VJ];
+    __shared__ float sF[VJM][3], sM[VJM][3];
+    __shared__ float sGX[9 * (VJM - 1) + 1];
+    __shared__ float sGrad[3 + 3 * (VJM - 1) + NBM + 3];
+    __shared__ int spar[VJM];
 
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64) void k2b_vertex_term_kernel(const VertexTermArg
     const float inv_bc2 = fast_rcp(co.y);
     for (int p = lane; p < P; p += 64) {
         const int group = p < 3 ? 0 : (p < 3 + D ? 1 : (p < 3 + D + NB ? 2 : 3));
-        const bool opt = (a.opt_mask >> group) & 1;
+        const bool opt = ((a.opt_mask >> group) & 1) && !(group == 2 && p - 3 - D < a.frozen_shape);
         const float g = opt ? a.grad_in[(size_t)f * P + p] + sGrad[p] : 0.f;
         if (a.grad_out) a.grad_out[(size_t)f * P + p] = g;
         float* x = group == 0 ? a.go_w + (size_t)f * 3 + p
@@ -292,8 +295,11 @@ __global__ __launch_bounds__(256) void k2b_adam_kernel(float* __restrict__ x, co
 
 hipError_t launch_vertex_term(const VertexTermArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0 || a.num_sel <= 0) return hipSuccess;
-    if (a.num_sel > VE) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k2b_vertex_term_kernel, dim3(a.num_frames), dim3(64), 0, stream, a);
+    if (a.num_sel > VE || a.num_joints < 1 || a.num_joints > 64 || a.num_betas > 32) return hipErrorInvalidValue;
+    if (a.num_joints <= kFitJoints && a.num_betas <= 16)
+        hipLaunchKernelGGL((k2b_vertex_term_kernel<kFitJoints, 16>), dim3(a.num_frames), dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k2b_vertex_term_kernel<64, 32>), dim3(a.num_frames), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -76,7 +76,11 @@ def main():
     j55 = gt.joints[:, :55].clone() + tt(synthetic.target_noise(T, 55, seed=3, scale=0.003))
     idx55 = torch.arange(55, dtype=torch.long)
 
+    only = sys.argv[1] if len(sys.argv) > 1 else None      # python oracle/gen_golden_smplx.py [case]: one case only
+
     def run(name, init, j3d, conf, seq_ind, num_iters, category, target_model_indices, freeze_betas=False):
+        if only is not None and name != only:
+            return
         B = j3d.shape[0]
         rec = RecorderX(model)
         fitter = WorldSpaceFitter(rec, step_size=1e-2, num_iters_first=num_iters if seq_ind == 0 else 7,
@@ -144,6 +148,12 @@ def main():
     warm = {k: truth[k] * 0.8 for k in FIELDS}
     warm["transl"] = truth["transl"] + 0.02
     run("all55_followup_frozen", warm, j55[:2], conf55, 3, 30, "GENERIC", idx55, freeze_betas=True)
+    # 4. vertex-selected joints among the targets (smplx "extra" joints = single mesh vertices, model indices >= 55): the loss
+    #    differentiates through blend shapes and skinning of those vertices (world_space.py:198-201)
+    idxv = torch.tensor(list(range(55)) + [55, 61, 75, 100, 126], dtype=torch.long)
+    jv = gt.joints[:, idxv].clone() + tt(synthetic.target_noise(T, 60, seed=5, scale=0.003))
+    confv = torch.ones(60); confv[[7, 8, 10, 11]] = 1.5; confv[[56, 58]] = 0.8
+    run("vertex_joints_zero_init", zero_init, jv[:2], confv, 0, 30, "GENERIC", idxv)
     print("smplx goldens written to", GOLDEN)
 
 

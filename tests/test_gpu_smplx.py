@@ -13,7 +13,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 PARAM_TOL = 1e-4
-CASES = ("all55_zero_init", "amass22_zero_init", "all55_followup_frozen")
+CASES = ("all55_zero_init", "amass22_zero_init", "all55_followup_frozen", "vertex_joints_zero_init")
 POSE_FIELDS = (("body_pose", 63), ("jaw_pose", 3), ("leye_pose", 3), ("reye_pose", 3), ("left_hand_pose", 45), ("right_hand_pose", 45))
 
 
@@ -308,3 +308,56 @@ def test_smplx_fit_does_not_depend_on_the_workgroup_shape():
         out = run(n)
         for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
             assert torch.equal(out[k], ref[k][:n]), (n, k)
+
+
+def test_smplx_vertex_term_gradient_matches_autograd():
+    """k2b_vertex_term on the 55-joint tree (the 64-joint / 32-coefficient instantiation of the kernel): loss and analytic
+    gradient of the joint loss on vertex-selected joints against torch autograd through the oracle's SMPL-X forward."""
+    from keypoints2body_amd import native, synthetic
+    from oracle.fit_torch import SMPLX_FIELDS, gmof
+    B = 3
+    sel = [0, 6, 20, 45, 71]
+    p = synthetic.make_poses_x(B, seed=21)
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32)
+    q = {k: t(getattr(p, k)).requires_grad_() for k in SMPLX_FIELDS}
+    joints = H.oracle_model_x()(**q).joints
+    gen = torch.Generator().manual_seed(3)
+    tgt = joints[:, [55 + e for e in sel]].detach() + 0.05 * torch.randn(B, len(sel), 3, generator=gen)
+    conf = torch.tensor([1.0, 0.7, 1.5, 1.0, 0.9])
+    lf = ((600.0 ** 2) * (conf ** 2).view(1, -1, 1) * gmof(joints[:, [55 + e for e in sel]] - tgt, 100.0)).sum(dim=(1, 2))
+    lf.sum().backward()
+    g_ref = torch.cat([q["global_orient"].grad] + [q[k].grad for k, _ in POSE_FIELDS] + [q["betas"].grad, q["expression"].grad,
+                       q["transl"].grad], dim=1).numpy()
+    pose = np.concatenate([getattr(p, k) for k, _ in POSE_FIELDS], axis=1)
+    shape = np.concatenate([p.betas, p.expression], axis=1)
+    loss, grad = native.vertex_term(H.native_model_x(), sel, tgt.cuda().contiguous(), conf.cuda(), 100.0, 600.0,
+                                    H.cuda(p.global_orient), H.cuda(pose), H.cuda(shape), H.cuda(p.transl))
+    np.testing.assert_allclose(loss.cpu().numpy(), lf.detach().numpy(), rtol=2e-5)
+    g = grad.cpu().numpy()
+    for name, sl in (("global_orient", slice(0, 3)), ("pose", slice(3, 165)), ("shape", slice(165, 185)), ("transl", slice(185, 188))):
+        scale = np.abs(g_ref[:, sl]).max()
+        assert np.abs(g[:, sl] - g_ref[:, sl]).max() / scale < 5e-5, name
+
+
+def test_smplx_vertex_joints_with_frozen_betas_and_per_frame_confidences():
+    """Vertex-selected joints on the 55-joint tree through k2b_fit_world: frozen betas stay put bit for bit while the expression
+    moves (the Adam tail's per-coefficient mask), and a (B, K) confidence tensor gives row by row the single-frame results."""
+    from keypoints2body_amd import native
+    d = H.load_smplx_case("vertex_joints_zero_init")
+    idx = [int(i) for i in d["target_model_indices"]]
+    go, pose, shape, tr = map(H.cuda, pack(d, "init_"))
+    shape = shape + 0.05
+    B, K = d["j3d"].shape[:2]
+    conf = H.cuda(np.random.default_rng(1).uniform(0.5, 1.5, (B, K)).astype(np.float32))
+    cfg = native.default_fit_config()
+    cfg.num_iters, cfg.freeze_betas, cfg.conf_per_frame = 10, 1, 1
+    cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
+    out = native.fit_world(H.native_model_x(), H.native_prior(), cfg, idx, H.cuda(d["j3d"]), conf, go, pose, shape, tr)
+    assert torch.equal(out["betas"][:, :10], shape[:, :10]) and not torch.equal(out["betas"][:, 10:], shape[:, 10:])
+    cfg.conf_per_frame = 0
+    for f in range(B):
+        sl = slice(f, f + 1)
+        one = native.fit_world(H.native_model_x(), H.native_prior(), cfg, idx, H.cuda(d["j3d"][sl]), conf[f].contiguous(), go[sl].contiguous(),
+                               pose[sl].contiguous(), shape[sl].contiguous(), tr[sl].contiguous())
+        for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+            assert torch.equal(out[k][sl], one[k]), (f, k)

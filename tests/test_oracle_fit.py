@@ -105,7 +105,7 @@ def test_oracle_reproduces_reference_shape_pass():
     #  returns betas ~ 0 even for targets generated with a distinct shape: pinned as it behaves)
 
 
-SMPLX_CASES = ("all55_zero_init", "amass22_zero_init", "all55_followup_frozen")
+SMPLX_CASES = ("all55_zero_init", "amass22_zero_init", "all55_followup_frozen", "vertex_joints_zero_init")
 
 
 @pytest.mark.parametrize("case", SMPLX_CASES)
