@@ -148,8 +148,8 @@ uint32_t k2b_fit_config_size(void);
  *
  *   model_joint_index [K] HOST int32: model joint fitted to target k (the reference's
  *       smpl_index / target_model_indices, world_space.py:194-201); values must be
- *       distinct.  Indices >= J name smplx's vertex-selected "extra" joints (24-joint models, at
- *       most 32 of them, at least one kinematic joint beside them): the call then queues TWO
+ *       distinct.  Indices >= J name smplx's vertex-selected "extra" joints (at
+ *       most 32 of them, at least one kinematic joint beside them; any supported tree): the call then queues TWO
  *       launches per iteration on the stream - the fused kernel in evaluate-only mode and the
  *       vertex-term kernel with its Adam tail - with no host work in between; conf may be per
  *       frame there too.
