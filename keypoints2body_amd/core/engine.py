@@ -147,17 +147,26 @@ def optimize_shape_pass(model, seq_config: SequenceOptimizeConfig, init_mean_sha
     conf = (conf if conf.dim() == 1 else conf[0])[list(corr_index)].contiguous()
     pose = torch.as_tensor(init_mean_pose, dtype=torch.float32).to(dev).expand(n, -1).contiguous()
     go, bp = pose[:, :3].contiguous(), pose[:, 3:].contiguous()
+    packed = getattr(m, "packed", False)             # SMPL-H / SMPL-X: all non-root joints in one pose vector, betas | expression
+    if packed:
+        bp = m.pack_pose(n, body_pose=bp[:, :3 * m.NUM_BODY_JOINTS]) if n > 0 else torch.zeros((0, 3 * (m.num_joints - 1)), device=dev)
     prior = pose_prior if pose_prior is not None else MaxMixturePrior(
         prior_folder="./data/models/", num_gaussians=seq_config.frame.pose_prior_num_gaussians, device=dev)
     jt, jd = m.native.joint_basis()                  # rest root joint = J_template[0] + J_dirs[0] . beta
     jt0 = torch.as_tensor(jt[root_model], device=dev)
     jd0 = torch.as_tensor(jd[root_model], device=dev)          # (3, NB)
+    n_extra = int(jd0.shape[1]) - int(torch.as_tensor(init_mean_shape).reshape(-1).shape[0])   # expression coefficients: kept at 0
+    if n_extra < 0:
+        raise ValueError(f"init_mean_shape has more coefficients than the model's {int(jd0.shape[1])}")
+    jd0 = jd0[:, :jd0.shape[1] - n_extra].contiguous()
 
     cfg = native.default_fit_config()
     cfg.num_iters, cfg.step_size = 1, 0.0
     cfg.sigma, cfg.joint_loss_weight = 1.0e8, 1.0             # plain squared error
     cfg.pose_prior_weight = cfg.angle_prior_weight = cfg.pose_preserve_weight = 0.0
     cfg.shape_prior_weight = float(seq_config.frame.shape_prior_weight)
+    if packed:
+        cfg.prior_pose_dims, cfg.num_betas_prior = 3 * m.NUM_BODY_JOINTS, m.num_betas
 
     betas = torch.as_tensor(init_mean_shape, dtype=torch.float32).to(dev).clone().reshape(1, -1).requires_grad_(True)
 
@@ -169,11 +178,14 @@ def optimize_shape_pass(model, seq_config: SequenceOptimizeConfig, init_mean_sha
             nb = b.shape[1]
             if n > 0:
                 transl = (y[:, root_target] - (jt0 + jd0 @ b[0])).contiguous()     # root alignment, (n,3)
+                shape = b.expand(n, -1)
+                if n_extra:
+                    shape = torch.cat((shape, torch.zeros((n, n_extra), device=dev)), dim=1)
                 r = native.fit_world(m.native, prior.native, cfg, list(smpl_index), targets, conf, go, bp,
-                                     b.expand(n, -1).contiguous(), transl, want_grad=True)
+                                     shape.contiguous(), transl, want_grad=True)
                 g = r["grad"]
                 g_beta = g[:, 3 + bp.shape[1]:3 + bp.shape[1] + nb].sum(dim=0)
-                g_transl = g[:, 3 + bp.shape[1] + nb:].sum(dim=0)
+                g_transl = g[:, 3 + bp.shape[1] + nb + n_extra:].sum(dim=0)
                 loss = r["loss"].sum()
             else:
                 g_beta, g_transl, loss = torch.zeros(nb, device=dev), torch.zeros(3, device=dev), torch.zeros((), device=dev)

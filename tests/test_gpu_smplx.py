@@ -361,3 +361,30 @@ def test_smplx_vertex_joints_with_frozen_betas_and_per_frame_confidences():
                                pose[sl].contiguous(), shape[sl].contiguous(), tr[sl].contiguous())
         for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
             assert torch.equal(out[k][sl], one[k]), (f, k)
+
+
+def test_smplx_sequence_with_the_reference_default_configuration():
+    """optimize_params_sequence with its DEFAULTS (shape pre-pass on, L-BFGS per frame, warm start) and a 55-joint model: the
+    pre-pass fits the 10 betas with the expression at zero, every frame comes back as SMPLXData with finite values, and the fit
+    explains the targets."""
+    import keypoints2body_amd as k2b
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.models.smpl_data import SMPLXData
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+    d = H.load_smplx_case("amass22_zero_init")
+    g = H.gmm_fixture()
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    model = BodyModel.synthetic_x(0)
+    seq = np.tile(d["j3d"], (3, 1, 1))[:4]
+    res = k2b.optimize_params_sequence(seq, body_model="smplx", joint_layout="AMASS", model=model, pose_prior=prior,
+                                       mean_params=(torch.zeros(1, 66), torch.zeros(1, 10)))
+    assert len(res) == 4 and all(isinstance(r.params, SMPLXData) for r in res)
+    for r in res:
+        assert torch.isfinite(r.loss) and all(torch.isfinite(getattr(r.params, k)).all() for k in ("betas", "body_pose", "expression", "transl"))
+    assert float(res[0].params.betas.abs().max()) > 1e-3          # the pre-pass moved the shape off the zero mean
+    with torch.no_grad():                                          # the zero pose, root aligned: where the fit starts
+        j0 = model(global_orient=torch.zeros(1, 3), body_pose=torch.zeros(1, 63), return_verts=False).joints[:, :22].cpu()
+    tgt = torch.tensor(seq[-1:])
+    err0 = (j0 - j0[:, :1] + tgt[:, :1] - tgt).norm(dim=-1).mean()
+    err = (res[-1].joints[:, :22].cpu() - tgt).norm(dim=-1).mean()
+    assert float(err) < 0.6 * float(err0), (float(err0), float(err))   # (30 + 10 L-BFGS iterations: the reference's defaults)
