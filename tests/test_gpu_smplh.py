@@ -109,3 +109,25 @@ def test_smplh_fitter_and_sequence_api_return_smplh_data():
         for k in FIELDS:
             assert torch.equal(getattr(out[i].params, k), getattr(want.params, k)), (i, k)
         prev = want.params
+
+
+@pytest.mark.parametrize("name", ["smplh", "smplx"])
+def test_packed_models_through_the_public_api_with_default_configurations(name):
+    """optimize_params_frame / optimize_params_sequence with their DEFAULT configurations (L-BFGS, shape pre-pass, warm start) and
+    a 52- / 55-joint model: the reference's data class for the model comes back, finite, with the full mesh."""
+    import keypoints2body_amd as k2b
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.models.smpl_data import SMPLHData, SMPLXData
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+    g = H.gmm_fixture()
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    model, cls, V = (BodyModel.synthetic_h(0), SMPLHData, 6890) if name == "smplh" else (BodyModel.synthetic_x(0), SMPLXData, 10475)
+    j3d = H.load_smplx_case("amass22_zero_init")["j3d"]
+    mean = (torch.zeros(1, 66), torch.zeros(1, 10))
+    for cfg in ({}, {"use_lbfgs": False}):
+        r = k2b.optimize_params_frame(j3d[0], body_model=name, joint_layout="AMASS", model=model, config=cfg, pose_prior=prior,
+                                      mean_params=mean)
+        assert isinstance(r.params, cls) and tuple(r.vertices.shape) == (1, V, 3) and torch.isfinite(r.loss)
+    rs = k2b.optimize_params_sequence(np.tile(j3d, (2, 1, 1))[:3], body_model=name, joint_layout="AMASS", model=model, pose_prior=prior,
+                                      mean_params=mean)
+    assert len(rs) == 3 and all(isinstance(x.params, cls) and torch.isfinite(x.loss) for x in rs)
