@@ -81,6 +81,7 @@ struct k2b_model {
     // tables of the tree fit kernel (any J <= 64), lane order = DFS pre-order
     float *tt_dt = nullptr, *tt_dd = nullptr;
     int *tt_tab = nullptr, *tt_anc = nullptr;
+    int tt_prior_dims = -1;                                  // what the prior columns of tt_tab currently describe (guarded by mu)
     std::vector<int> tt_lane_of;                             // lane of every joint
     int groups_a = 0;                                        // GA = ceil(J / 8)
     k2b::k2b_half* wsA2 = nullptr;                           // per-frame A operand of the tile kernel
@@ -656,9 +657,12 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
         if (chain_len > 1 && chain_iters > tc.num_iters) tc.num_iters = chain_iters;
         if (const int rc = adam_table(model, &tc, (hipStream_t)stream, &coef); rc != K2B_OK) return rc;
     }
-    {   // prior columns of the lane table (depend on prior_dims): uploaded once per model and value
-        static thread_local std::pair<const k2b_model*, int> last{nullptr, -1};
-        if (last.first != model || last.second != prior_dims) {
+    {   // prior columns of the lane table (depend on prior_dims): uploaded when the value changes.  The state lives in the
+        // model (a per-thread cache keyed by the handle's address would go stale when a handle is destroyed and another one
+        // created at the same address, or when two threads use one model with different values); launches of one model with
+        // DIFFERENT prior_pose_dims must not be in flight on different streams at once.
+        std::lock_guard<std::mutex> lk(model->mu);
+        if (model->tt_prior_dims != prior_dims) {
             std::vector<int> cols((size_t)64 * 3, -1);
             for (int i = 0; i < prior_dims; ++i) {               // prior dimension i = component i % 3 of joint 1 + i / 3
                 cols[i * 3 + 0] = model->tt_lane_of[1 + i / 3];
@@ -669,7 +673,7 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
             HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
             for (int l = 0; l < 64; ++l)
                 HIP_TRY(hipMemcpy(model->tt_tab + l * 8 + 4, cols.data() + l * 3, 3 * sizeof(int), hipMemcpyHostToDevice));
-            last = {model, prior_dims};
+            model->tt_prior_dims = prior_dims;
         }
     }
     a.dt = model->tt_dt; a.dd = model->tt_dd; a.tab = model->tt_tab; a.anc = model->tt_anc;

@@ -388,3 +388,20 @@ def test_smplx_sequence_with_the_reference_default_configuration():
     err0 = (j0 - j0[:, :1] + tgt[:, :1] - tgt).norm(dim=-1).mean()
     err = (res[-1].joints[:, :22].cpu() - tgt).norm(dim=-1).mean()
     assert float(err) < 0.6 * float(err0), (float(err0), float(err))   # (30 + 10 L-BFGS iterations: the reference's defaults)
+
+
+def test_prior_width_can_change_between_calls_on_one_model():
+    """The lane table's prior columns follow k2b_fit_config.prior_pose_dims from call to call (state kept in the model handle)."""
+    from keypoints2body_amd import native
+    d = H.load_smplx_case("all55_zero_init")
+    idx = [int(i) for i in d["target_model_indices"]]
+    go, pose, shape, tr = map(H.cuda, pack(d, "init_"))
+
+    def run(dims):
+        cfg = native.default_fit_config()
+        cfg.num_iters, cfg.prior_pose_dims, cfg.num_betas_prior = 8, dims, 10
+        return native.fit_world(H.native_model_x(), H.native_prior(), cfg, idx, H.cuda(d["j3d"]), H.cuda(d["conf"]), go, pose, shape, tr)
+
+    a, b, c = run(63), run(60), run(63)
+    assert torch.equal(a["body_pose"], c["body_pose"]) and torch.equal(a["loss"], c["loss"])
+    assert not torch.equal(a["body_pose"], b["body_pose"])
