@@ -405,3 +405,69 @@ def test_prior_width_can_change_between_calls_on_one_model():
     a, b, c = run(63), run(60), run(63)
     assert torch.equal(a["body_pose"], c["body_pose"]) and torch.equal(a["loss"], c["loss"])
     assert not torch.equal(a["body_pose"], b["body_pose"])
+
+
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_smplx_random_configurations_match_oracle(seed):
+    """Seeded sweep over the configuration space of the tree kernel against the oracle (itself pinned to the reference on the
+    golden cases): batch size (1-9 frames: 1-8 waves per workgroup, uneven component shares), iteration count, target subset and
+    order (body, face, fingers), confidences incl. zeros and > 1, every loss weight (some zero: no mixture at all), sigma,
+    frozen betas, first / follow-up frame, zero / perturbed / large starts.  Parameters within 1e-4, last loss 2e-4 relative."""
+    from keypoints2body_amd import native, synthetic
+    from oracle.fit_torch import FitWeights, SMPLX_FIELDS, fit_world_adam_smplx
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 10))
+    K = int(rng.integers(8, 56))
+    idx = sorted(rng.choice(55, size=K, replace=False).tolist())
+    idx = [idx[i] for i in rng.permutation(K)]
+    if 0 not in idx:
+        idx[0] = 0
+    p = synthetic.make_poses_x(B, seed=200 + seed)
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32)
+    truth = {k: t(getattr(p, k)) for k in SMPLX_FIELDS}
+    kind = ("zeros", "perturbed", "large")[seed % 3]
+    if kind == "zeros":
+        init = {k: torch.zeros_like(v) for k, v in truth.items()}
+    elif kind == "perturbed":
+        init = {k: v * 0.7 + 0.02 for k, v in truth.items()}
+        init["body_pose"][:, 6:12] = 0.0
+    else:
+        init = {k: v * 1.5 for k, v in truth.items()}
+        axis = t(rng.standard_normal((B, 3))); init["global_orient"] = axis / axis.norm(dim=1, keepdim=True) * 3.1
+        init["betas"] = t(rng.uniform(-2, 2, (B, 10)))
+    oracle = H.oracle_model_x()
+    with torch.no_grad():
+        j3d = oracle(**truth).joints[:, idx] + t(0.01 * rng.standard_normal((B, K, 3)))
+        j0 = oracle(**{k: v for k, v in init.items() if k != "transl"}).joints
+    init["transl"] = (j3d[:, idx.index(0)] - j0[:, 0]) + 0.01
+    conf = t(rng.choice([0.0, 0.5, 1.0, 1.5], size=K, p=[0.15, 0.2, 0.45, 0.2])); conf[idx.index(0)] = 1.0
+    pick = lambda *v: float(rng.choice(v))
+    weights = dict(sigma=pick(30.0, 100.0, 300.0), pose_prior_weight=pick(0.0, 4.78 * 1.5, 12.0), shape_prior_weight=pick(0.0, 5.0, 20.0),
+                   angle_prior_weight=pick(0.0, 15.2), joint_loss_weight=pick(100.0, 600.0), pose_preserve_weight=pick(1.0, 5.0))
+    iters, seq_ind, freeze = int(rng.integers(3, 26)), int(seed % 2) * 3, bool(seed % 4 == 0)
+    ref, ref_loss, _, _, _ = fit_world_adam_smplx(oracle, H.oracle_prior(), init, j3d, conf if seed % 3 else None, num_iters=iters,
+                                                  seq_ind=seq_ind, model_idx=idx, weights=FitWeights(**weights), freeze_betas=freeze)
+    cfg = native.default_fit_config()
+    cfg.num_iters = iters
+    for k, v in weights.items():
+        setattr(cfg, k, v)
+    if seq_ind == 0:
+        cfg.pose_preserve_weight = 0.0
+    cfg.freeze_betas, cfg.prior_pose_dims, cfg.num_betas_prior = int(freeze), 63, 10
+    pose0 = torch.cat([init[k] for k, _ in POSE_FIELDS], dim=1)
+    shape0 = torch.cat([init["betas"], init["expression"]], dim=1)
+    out = native.fit_world(H.native_model_x(), H.native_prior(), cfg, idx, j3d.cuda().contiguous(), conf.cuda() if seed % 3 else None,
+                           init["global_orient"].cuda().contiguous(), pose0.cuda().contiguous(), shape0.cuda().contiguous(),
+                           init["transl"].cuda().contiguous())
+    want_pose = torch.cat([ref[k] for k, _ in POSE_FIELDS], dim=1)
+    want_shape = torch.cat([ref["betas"], ref["expression"]], dim=1)
+    tag = (seed, kind, B, iters, K, weights["pose_prior_weight"])
+    worst = 0.0
+    for key, want in (("global_orient", ref["global_orient"]), ("body_pose", want_pose), ("betas", want_shape), ("transl", ref["transl"])):
+        err = (out[key].cpu() - want).abs().max().item()
+        worst = max(worst, err)
+        assert err < PARAM_TOL, (tag, key, err)
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), ref_loss.numpy(), rtol=2e-4, err_msg=str(tag))
+    if freeze:
+        assert torch.equal(out["betas"][:, :10].cpu(), init["betas"])
+    print(f"smplx random configuration {tag}: worst parameter deviation {worst:.2e}")
