@@ -20,7 +20,8 @@
  *     k2b_model_reserve() pre-sizes it so that later calls never do); k2b_fit_world on the
  *     FIRST use of an (iterations, lr, beta1, beta2) combination per model (blocking upload
  *     of the Adam bias table; at most 64 tables are kept, least recently used evicted after
- *     a stream sync); k2b_vertex_term when the joint selection changes (stream sync + copy);
+ *     a stream sync).  k2b_vertex_term never synchronises: its joint selection travels by value in
+ *     the kernel arguments;
  *   - buffers are caller-owned; inputs are never written; handles may be shared by
  *     threads as long as concurrent calls use different streams AND different
  *     workspaces (one workspace per handle: serialise calls on one handle).
