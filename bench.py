@@ -4,15 +4,22 @@
 
     python bench.py --gpus N --steps K --warmup W [--total-frames T | --frames F] [--iters I] [--model smpl|smplx]
 
+``--gpus N > 1`` without a launcher (no WORLD_SIZE in the environment) starts its own N ranks with
+``python -m torch.distributed.run`` before touching the GPU and relays rank 0's line; under a launcher
+(the driver's ``torch.distributed.run ... bench.py --gpus N``) the process is one rank.
+
 Default workload = the north-star headline: ONE synthetic AMASS sequence of T = 4096 frames whose
 frames shard over the N ranks in contiguous blocks (``parallel.shard_bounds``; strong scaling: the
 total work is fixed, N = 1 fits all 4096 frames on one GPU).  ``--frames F`` switches to weak scaling
-(F frames per GPU).  One "step" = one pass of the hot path over the rank's frames: the fused fit
-kernel (all Adam iterations), the final LBS forward (joints + all vertices per frame) and, for N > 1,
-the all-gather of the fitted parameters over RCCL (enqueued behind the fit, waited for after the LBS
-launches).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; the
-1024-frames-per-GPU figure of BASELINE configs[1] rides along under ``weak_1024`` (measured in the
-same process after the timed region).  See DESIGN.md "Measurement" for `roofline` / `cpu_baseline`.
+(F frames per GPU).  One "step" = one pass of the hot path over the rank's frames =
+``parallel.fit_forward_exchange``, the function the public ``optimize_params_sequence`` runs for
+independent frames: the fused fit kernel (all Adam iterations), the all-gather of the fitted parameters
+over RCCL (N > 1: enqueued behind the fit, on RCCL's stream), the final LBS forward over the rank's OWN
+block (joints + all vertices per frame), the all-gather of the joints, the wait for both.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line; BASELINE configs[1] (1024 frames
+per GPU), configs[2] (10 000-frame sequence, sharded) and configs[3] (SMPL-X, 1024 frames per GPU) ride
+along under ``weak_1024`` / ``seq_10000`` / ``smplx_1024`` (measured in the same process after the timed
+region, same K / W / repeats).  See DESIGN.md "Measurement" for `roofline` / `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -36,7 +43,8 @@ sys.path.insert(0, str(REPO))
 FIT_FLOP_PER_FRAME_ITER = {"smpl": 0.11e6, "smplx": 0.106e6}
 FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 HBM_PEAK_GBS = 8000.0
-ROUND = "r02"
+ROUND = "r03"
+LBS_KERNELS = "k2b_pose_setup_kernel+k2b_lbs_tile_kernel+k2b_gather_joints_kernel"
 PREWARM_S = 0.3        # seconds of untimed load before the warm-up steps (device clock ramp, see measure())
 
 
@@ -68,7 +76,8 @@ def parse():
     ap.add_argument("--iters", type=int, default=100, help="Adam iterations per frame")
     ap.add_argument("--model", choices=("smpl", "smplx"), default="smpl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1024-frames-per-GPU measurement")
+    ap.add_argument("--no-weak-line", action="store_true",
+                    help="skip the secondary measurements (weak_1024, seq_10000, smplx_1024)")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed B=1 fits per thread setting of the CPU baseline")
     return ap.parse_args()
 
@@ -188,7 +197,7 @@ def cpu_baseline(iters, runs):
 def read_traffic(model_kind, frames):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md); only known for the
     frame counts that were profiled."""
-    for name in (f"traffic_{ROUND}.json", "traffic_r01.json"):
+    for name in (f"traffic_{ROUND}.json", "traffic_r02.json", "traffic_r01.json"):
         tfile = REPO / "profiles" / name
         if not tfile.exists():
             continue
@@ -203,8 +212,31 @@ def read_traffic(model_kind, frames):
     return None, None, None
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (``torch.distributed.run``, one per GPU,
+    rendezvous on 127.0.0.1) BEFORE this process has touched the GPU, relay their output (rank 0 prints the JSON line) and
+    return the launcher's exit code (non-zero if any rank failed).  Nothing is re-exec'ed: the ranks are children."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        backend = os.environ.get("K2B_BENCH_BACKEND", "nccl")
+        have = torch.cuda.device_count()                     # counting devices does not initialise the GPU
+        if backend == "nccl" and have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible (RCCL needs one per rank)")
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,13 +261,13 @@ def main():
 
     from keypoints2body_amd import native
     from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
-    from keypoints2body_amd.parallel import gather_fit_outputs, shard_bounds
+    from keypoints2body_amd.parallel import fit_forward_exchange, shard_bounds
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
     repeats = max(1, int(args.repeats))
 
-    def measure(total, weak, steps, warmup):
+    def measure(total, weak, steps, warmup, model_kind):
         """Time `steps` passes over this rank's share of `total` frames (weak: `total` = frames per GPU)."""
         if weak:
             T, start, stop, per = total * world, rank * total, (rank + 1) * total, total
@@ -243,32 +275,42 @@ def main():
             T = total
             start, stop = shard_bounds(T, world, rank)
             per = (T + world - 1) // world
-        model, prior, j3d, init = build_problem(T, start, stop, 1000, device, args.model)
+        model, prior, j3d, init = build_problem(T, start, stop, 1000, device, model_kind)
         fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=args.iters, num_iters_followup=args.iters,
-                                  use_lbfgs=False, joints_category="AMASS" if args.model == "smpl" else "GENERIC",
+                                  use_lbfgs=False, joints_category="AMASS" if model_kind == "smpl" else "GENERIC",
                                   device=device, pose_prior=prior)
         cfg = fitter._config(0, 600.0, 5.0, False, False)
         K = j3d.shape[1]
-        if args.model == "smplx":
+        idx = list(range(K))
+        if model_kind == "smplx":
             cfg.prior_pose_dims, cfg.num_betas_prior = 63, 10
             init = fitter.packed_init(init)
-        fit_ev, lbs_ev = [], []
+        fit_ev, lbs_ev, xch_ev = [], [], []
 
         def step(record=False, comm=True):
-            e0, e1, e2 = ev(), ev(), ev()
+            """ONE pass of the hot path over this rank's block = ``parallel.fit_forward_exchange``, the very function the public
+            ``optimize_params_sequence`` runs for independent frames: fit launch, parameter all-gather enqueued on RCCL's stream,
+            final forward over the OWN block, joints all-gather, wait."""
+            e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+
+            def fit_fn():
+                out = fitter.fit_params(cfg, j3d, init, idx)
+                e1.record()
+                return out
+
+            def forward_fn(out):
+                jv = fitter.final_forward(out)
+                e2.record()
+                return jv
+
             e0.record()
-            out = fitter.fit_params(cfg, j3d, init, list(range(K)))
-            e1.record()
-            # the parameter exchange is enqueued behind the fit and runs on RCCL's stream under the LBS launches
-            gathered, work = gather_fit_outputs(out, dist, pad_to=per, async_op=True) if (dist is not None and comm) else (None, None)
-            joints, verts = fitter.final_forward(out)
-            e2.record()
-            if work is not None:
-                work.wait()
+            ex = fit_forward_exchange(fit_fn, forward_fn, dist if comm else None, pad_to=per)
+            e3.record()
             if record:
                 fit_ev.append((e0, e1))
                 lbs_ev.append((e1, e2))
-            return out, joints, verts, gathered
+                xch_ev.append((e2, e3))
+            return ex["local"], ex["joints"], ex["vertices"]
 
         # clock ramp: a fresh process starts at a low device clock and needs ~0.1 s of load to reach the steady one (a
         # 1024-frame run with only W = 30 warm-up steps = 9 ms of work measured 0.391 ms/step, the same steps behind
@@ -291,13 +333,13 @@ def main():
         # median of nine short windows does not depend on it.
         blocks = []
         for rep in range(repeats):
-            del fit_ev[:], lbs_ev[:]
+            del fit_ev[:], lbs_ev[:], xch_ev[:]
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
-                out, joints, verts, gathered = step(record=True)
+                out, joints, verts = step(record=True)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
@@ -306,35 +348,61 @@ def main():
                 tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 elapsed = float(tmax.item())
-            blocks.append((elapsed, float(np.mean([a.elapsed_time(b) for a, b in fit_ev])),      # HIP events on the launch stream
-                           float(np.mean([a.elapsed_time(b) for a, b in lbs_ev]))))
+            mean_ms = lambda evs: float(np.mean([a.elapsed_time(b) for a, b in evs]))      # HIP events on the launch stream
+            blocks.append((elapsed, mean_ms(fit_ev), mean_ms(lbs_ev), mean_ms(xch_ev)))
         order = sorted(range(repeats), key=lambda i: blocks[i][0])
-        elapsed, fit_ms, lbs_ms = blocks[order[repeats // 2]]                  # the median block (same block for all three figures)
+        elapsed, fit_ms, lbs_ms, xch_ms = blocks[order[repeats // 2]]           # the median block (same block for all figures)
         n_local = stop - start
+        jl = joints if joints.shape[0] == n_local else joints[rank * per: rank * per + n_local]   # gathered joints: own rows
         res = {
-            "T": T, "frames_local": n_local, "elapsed": elapsed, "model": model,
-            "fit_ms": fit_ms, "lbs_ms": lbs_ms,
+            "T": T, "frames_local": n_local, "elapsed": elapsed, "model": model, "kind": model_kind, "weak": weak,
+            "fit_ms": fit_ms, "lbs_ms": lbs_ms, "exchange_ms": xch_ms,
             "block_ms": [round(1e3 * b[0], 3) for b in blocks],
-            "err_cm": float((joints[:, :K] - j3d).norm(dim=-1).mean().item() * 100) if n_local else 0.0,
+            "err_cm": float((jl[:, :K] - j3d).norm(dim=-1).mean().item() * 100) if n_local else 0.0,
             "loss": float(out["loss"].mean()) if n_local else 0.0,
         }
         return res
 
+    def fractions(r):
+        """Roofline fractions of one measurement: fit kernel against the fp32 vector peak, the LBS launches against 8 TB/s."""
+        F = r["frames_local"]
+        flop_iter = FIT_FLOP_PER_FRAME_ITER[r["kind"]]
+        lbs_bytes = lbs_bytes_per_frame(r["model"])
+        fit_tflops = flop_iter * args.iters * F / (r["fit_ms"] * 1e-3) / 1e12
+        lbs_gbs = lbs_bytes * F / (r["lbs_ms"] * 1e-3) / 1e9
+        return flop_iter, lbs_bytes, fit_tflops, lbs_gbs
+
+    def sub_line(r, workload):
+        _, _, fit_tflops, lbs_gbs = fractions(r)
+        d = {"workload": workload, "value": round(r["T"] * args.steps / r["elapsed"], 1), "unit": "frames/s",
+             "scaling": "weak" if r["weak"] else "strong", "total_frames": r["T"], "frames_rank0": r["frames_local"],
+             "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
+             "fit_ms": round(r["fit_ms"], 4), "lbs_ms": round(r["lbs_ms"], 4),
+             "fit_frac_fp32": round(fit_tflops / FP32_PEAK_TFLOPS, 4), "lbs_frac_hbm": round(lbs_gbs / HBM_PEAK_GBS, 4),
+             "mean_joint_error_cm": round(r["err_cm"], 3)}
+        if world > 1:
+            d["exchange_ms"] = round(r["exchange_ms"], 4)
+        return d
+
     weak = args.frames is not None
-    main_res = measure(args.frames if weak else args.total_frames, weak, args.steps, args.warmup)
-    weak_res = None
+    main_res = measure(args.frames if weak else args.total_frames, weak, args.steps, args.warmup, args.model)
+    extra = {}
     if not weak and not args.no_weak_line and args.model == "smpl":
-        weak_res = measure(1024, True, args.steps, args.warmup)
+        # the other BASELINE configs ride along in the same process (same steps / warm-up / repeats; each builds its own problem)
+        extra["weak_1024"] = sub_line(measure(1024, True, args.steps, args.warmup, "smpl"),
+                                      "BASELINE configs[1]: 1024 frames per GPU (weak scaling), same model and settings")
+        extra["seq_10000"] = sub_line(measure(10000, False, args.steps, args.warmup, "smpl"),
+                                      f"BASELINE configs[2]: 10 000-frame AMASS-style sequence, frames sharded over {world} GPU(s)")
+        extra["smplx_1024"] = sub_line(measure(1024, True, args.steps, args.warmup, "smplx"),
+                                       "BASELINE configs[3]: SMPL-X (55 joints, V=10475, betas | expression = 20), 1024 frames per GPU, "
+                                       "all 55 kinematic joints observed, 100 Adam iters")
 
     if rank == 0:
         r = main_res
         model = r["model"]
         F = r["frames_local"]
         ms_per_step = r["elapsed"] / args.steps * 1e3
-        flop_iter = FIT_FLOP_PER_FRAME_ITER[args.model]
-        lbs_bytes = lbs_bytes_per_frame(model)
-        fit_tflops = flop_iter * args.iters * F / (r["fit_ms"] * 1e-3) / 1e12
-        lbs_gbs = lbs_bytes * F / (r["lbs_ms"] * 1e-3) / 1e9
+        flop_iter, lbs_bytes, fit_tflops, lbs_gbs = fractions(r)
         traffic, traffic_lbs, traffic_src = read_traffic(args.model, F)
         n = model.native
         shape = (f"{'SMPL' if args.model == 'smpl' else 'SMPL-X'}-shaped model (V={n.num_vertices}, J={n.num_joints}, "
@@ -367,6 +435,8 @@ def main():
                 "total_frames": r["T"], "frames_rank0": F, "adam_iters": args.iters,
                 "parallelism": f"frames sharded x{world}",
                 "prewarm_s": PREWARM_S,          # untimed load before the W warm-up steps (device clock ramp)
+                "step": "parallel.fit_forward_exchange (the function optimize_params_sequence runs for independent frames): "
+                        "fit own block, parameter all-gather under the final forward of the own block, joints all-gather",
             },
             # dominant kernel: the fused fit.  It never touches HBM inside its loop; its bound is fp32 vector-ALU issue
             # (DESIGN §4.1), so the peak is the fp32 VALU peak (= the fp32-input MFMA peak), not an f16 matrix peak.
@@ -377,7 +447,7 @@ def main():
                 "note": f"algorithmic fp32 flops ({flop_iter / 1e6:.3f} MFLOP per frame-iteration) against the fp32 vector peak",
             },
             "roofline_lbs": {
-                "kernel": "k2b_pose_setup_kernel+k2b_lbs_tile_kernel+k2b_gather_joints_kernel", "bound": "hbm",
+                "kernel": LBS_KERNELS, "bound": "hbm",
                 "achieved": round(lbs_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(lbs_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_lbs, "avg_launch_ms": round(r["lbs_ms"], 4),
                 "bytes_per_frame": lbs_bytes,
@@ -385,19 +455,11 @@ def main():
             },
             "quality": {"mean_joint_error_cm": round(r["err_cm"], 3), "mean_final_loss": round(r["loss"], 2)},
         }
+        if world > 1:
+            line["exchange_ms"] = round(r["exchange_ms"], 4)    # what the step waits for the collectives behind the forward
         if traffic_src:
             line["roofline"]["traffic_source"] = line["roofline_lbs"]["traffic_source"] = "profiles/" + traffic_src
-        if weak_res is not None:
-            w = weak_res
-            line["weak_1024"] = {
-                "workload": "BASELINE configs[1]: 1024 frames per GPU (weak scaling), same model and settings",
-                "value": round(w["T"] * args.steps / w["elapsed"], 1), "unit": "frames/s",
-                "ms_per_step": round(w["elapsed"] / args.steps * 1e3, 4),
-                "fit_ms": round(w["fit_ms"], 4), "lbs_ms": round(w["lbs_ms"], 4),
-                "fit_frac_fp32": round(flop_iter * args.iters * w["frames_local"] / (w["fit_ms"] * 1e-3) / 1e12
-                                       / FP32_PEAK_TFLOPS, 4),
-                "lbs_frac_hbm": round(lbs_bytes * w["frames_local"] / (w["lbs_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            }
+        line.update(extra)
         if world == 1 and not args.no_cpu_baseline and args.model == "smpl":
             line["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_runs)
         print(json.dumps(line), flush=True)

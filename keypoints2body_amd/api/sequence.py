@@ -11,11 +11,13 @@ Two execution modes, both with the reference's per-frame semantics:
 * ``use_previous_frame_init=False``: every frame starts from the same initial parameters, so
   the frames are independent and are fitted in TWO launches: frame 0
   (``num_iters_first``, no preserve term) and frames 1..T-1 as one batch
-  (``num_iters_followup``, preserve term towards the shared initial pose).  When a
-  ``torch.distributed`` process group is initialised (one process per GPU, ``torchrun``), that batch
-  is SHARDED over the ranks (``parallel.fit_frames_sharded``: contiguous blocks, no collective during
-  the iterations, one all-gather of the fitted parameters); every rank then runs the cheap final
-  forward over the whole sequence and returns the full, identical list of results.
+  (``num_iters_followup``, preserve term towards the shared initial pose) + ONE final forward.  When a
+  ``torch.distributed`` process group is initialised (one process per GPU, ``torchrun``), the T frames are cut
+  into contiguous blocks, one per rank (``parallel.fit_forward_exchange``: no collective during the iterations;
+  the all-gather of the fitted parameters is enqueued under the rank's final forward over ITS block, the joints
+  follow).  Every rank returns parameters, joints and loss of all frames; vertices stay on the rank that produced
+  them (``vertices=None`` elsewhere) unless ``gather_vertices=True``.  Frame 0 is fitted once, by
+  the rank that owns it.  ``bench.py`` times this very function.
 """
 from __future__ import annotations
 
@@ -40,44 +42,101 @@ def _process_group():
     return None
 
 
-def _fit_independent_frames(est, prev: BodyModelParams, xyz, conf, model_indices, dist):
-    """Frames that all start from `prev` (seq_ind >= 1 semantics), fitted in one batched launch or, under a
-    process group, in one launch per rank over its contiguous block + ONE all-gather of the parameters
-    (reference seam: the frame loop of ``api/sequence.py:214-281`` with ``use_previous_frame_init=False``)."""
-    n = xyz.shape[0]
-    if dist is None:
-        return est.fit_batch(_repeat_params(prev, n), xyz, conf, seq_ind=1, target_model_indices=model_indices,
-                             per_frame_conf=True)
-    from ..parallel import fit_frames_sharded
-    pose_dim, num_betas = int(prev.body_pose.shape[-1]), int(prev.betas.shape[-1])
+def _packed_widths(est, prev: BodyModelParams):
+    """Columns of the kernel-layout pose / shape vectors the fitter returns: for packed 52- / 55-joint models ALL non-root
+    joints and betas | expression (162 / 153 and 20 values), else the widths of `prev` (63 / 69 and 10)."""
+    smpl = getattr(est.fitter, "smpl", None)
+    if smpl is not None and getattr(smpl, "packed", False):
+        return 3 * (int(smpl.num_joints) - 1), int(smpl.num_shape)
+    return int(prev.body_pose.shape[-1]), int(prev.betas.shape[-1])
+
+
+def _fit_independent_frames(est, prev: BodyModelParams, xyz, conf, model_indices, dist, gather_vertices: bool = False):
+    """The frame loop of ``api/sequence.py:214-281`` with ``use_previous_frame_init=False``: every frame starts from
+    `prev`; frame 0 with ``seq_ind == 0`` semantics (``num_iters_first``, no preserve term), frames 1..T-1 with
+    ``seq_ind >= 1`` semantics.  The T frames are cut into contiguous blocks, one per rank (one block = everything without a
+    process group); a rank fits ITS block (frame 0 on the rank that owns it: one launch for it, one for the others), runs the
+    final forward over ITS block only, and the ranks exchange the fitted parameters (enqueued under the forward) and the
+    joints (``parallel.fit_forward_exchange``).  Vertices stay on the rank that produced them - ``vertices=None`` in the
+    results of other ranks' frames - unless ``gather_vertices`` asks for the second exchange.
+
+    Returns ``(params dict over all T frames, joints (T, .), vertex_of(i) -> (1, V, 3) | None, loss (T,))``."""
+    from ..parallel import fit_forward_exchange, shard_bounds, unpack_outputs, valid_rows
+    T = xyz.shape[0]
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    start, stop = shard_bounds(T, world, rank)
+    per = (T + world - 1) // world
+    pose_dim, num_shape = _packed_widths(est, prev)
     device = xyz.device
 
-    def fit_block(sl: slice):
-        b = sl.stop - sl.start
-        if b <= 0:
+    def fit_block():
+        parts = []
+        if start == 0 and stop > 0:
+            o, _, _, _ = est.fit_batch(_repeat_params(prev, 1), xyz[0:1], conf[0], seq_ind=0,
+                                       target_model_indices=model_indices, per_frame_conf=False, run_forward=False)
+            parts.append(o)
+        lo = max(start, 1)
+        if stop > lo:
+            o, _, _, _ = est.fit_batch(_repeat_params(prev, stop - lo), xyz[lo:stop], conf[lo:stop], seq_ind=1,
+                                       target_model_indices=model_indices, per_frame_conf=True, run_forward=False)
+            parts.append(o)
+        if not parts:                                     # empty trailing shard: zero rows of the right widths
             e = lambda c: torch.zeros((0, c), dtype=torch.float32, device=device)
-            return {"global_orient": e(3), "body_pose": e(pose_dim), "betas": e(num_betas), "transl": e(3),
+            return {"global_orient": e(3), "body_pose": e(pose_dim), "betas": e(num_shape), "transl": e(3),
                     "loss": torch.zeros((0,), dtype=torch.float32, device=device)}
-        out, _, _, _ = est.fit_batch(_repeat_params(prev, b), xyz[sl], conf[sl], seq_ind=1,
-                                     target_model_indices=model_indices, per_frame_conf=True, run_forward=False)
-        return out
+        if len(parts) == 1:
+            return parts[0]
+        return {k: torch.cat([p[k] for p in parts], dim=0).contiguous() for k in parts[0]}
 
-    out = fit_frames_sharded(fit_block, n, num_betas, pose_dim, dist)
-    joints, verts = est.fitter.final_forward(out)        # every rank: whole sequence, identical bits
-    return out, joints, verts, out["loss"]
+    def forward_block(out):
+        if out["loss"].shape[0] == 0:
+            return None, None
+        return est.fitter.final_forward(out)
+
+    ex = fit_forward_exchange(fit_block, forward_block, dist, pad_to=per, gather_vertices=gather_vertices)
+    if world == 1:
+        out, joints, verts = ex["local"], ex["joints"], ex["vertices"]
+        return out, joints, (lambda i: verts[i: i + 1]), out["loss"]
+    keep = valid_rows(T, world, device)
+    out = unpack_outputs(ex["packed"].index_select(0, keep), num_shape, pose_dim)
+    joints, verts = ex["joints"], ex["vertices"]
+    if joints is None:                                    # this rank's shard was empty: it still receives everyone's joints
+        raise RuntimeError("more ranks than frames: every rank must own at least one frame of the sequence")
+    joints = joints.index_select(0, keep)
+    if ex["vertices_gathered"]:
+        verts = verts.index_select(0, keep)
+        vertex_of = lambda i: verts[i: i + 1]
+    else:
+        vertex_of = lambda i: verts[i - start: i - start + 1] if start <= i < stop else None
+    return out, joints, vertex_of, out["loss"]
 
 
-def _repeat_params(p: BodyModelParams, n: int) -> SMPLData:
-    rep = lambda x: torch.as_tensor(x, dtype=torch.float32).expand(n, -1).contiguous()
-    return SMPLData(betas=rep(p.betas), global_orient=rep(p.global_orient), body_pose=rep(p.body_pose),
-                    transl=rep(p.transl))
+def _repeat_params(p: BodyModelParams, n: int) -> BodyModelParams:
+    """`p` (one row) as the start of n frames, every array field repeated and the data class kept - the reference hands
+    `prev` itself (``SMPLHData`` / ``SMPLXData`` with hands, jaw, eyes, expression) to every frame (api/sequence.py:270-281)."""
+    import dataclasses as dc
+    changes = {}
+    for f in dc.fields(p):
+        v = getattr(p, f.name)
+        if f.name == "metadata" or v is None or isinstance(v, (dict, str)):
+            continue
+        t = torch.as_tensor(v, dtype=torch.float32)
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        changes[f.name] = t.expand(n, -1).contiguous()
+    return dc.replace(p, **changes)
 
 
 def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParams] = None,
                              body_model: ModelType = "smpl", joint_layout: Optional[str] = None, model=None,
                              config: Optional[SequenceOptimizeConfig | dict] = None, device=None,
-                             pose_prior=None, mean_params: Optional[tuple] = None) -> list[BodyModelFitResult]:
-    """Optimise body parameters for a motion sequence; results in temporal order."""
+                             pose_prior=None, mean_params: Optional[tuple] = None,
+                             gather_vertices: bool = False) -> list[BodyModelFitResult]:
+    """Optimise body parameters for a motion sequence; results in temporal order.
+
+    ``gather_vertices`` only matters for independent frames under a ``torch.distributed`` process group: every rank
+    returns parameters, joints and loss of ALL frames, but the vertices of its own block only (``vertices=None``
+    elsewhere) unless this asks for the second all-gather (82.7 KB per frame)."""
     device = common.resolve_device(device)
     seq_cfg = sequence_config_from(config)
     frame_cfg = seq_cfg.frame
@@ -138,15 +197,15 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
     # independent frames: all start from `prev` (api/sequence.py:214-281 with use_previous_frame_init=False)
     if frame_cfg.coordinate_mode == "world" and prev.transl is None:
         prev = _with_root_aligned_transl(prev, xyz[0:1], model, frame_cfg, device)
-    results.append(engine.fit_frame(init_params=prev, j3d=xyz[0:1], conf_3d=conf[0], seq_ind=0,
-                                    target_model_indices=model_indices))
     if not hasattr(est.fitter, "fit_batch"):          # camera-space fitter: one call per frame
-        for idx in range(1, T):
+        for idx in range(T):
             results.append(engine.fit_frame(init_params=prev, j3d=xyz[idx: idx + 1], conf_3d=conf[idx], seq_ind=idx,
                                             target_model_indices=model_indices))
         return results
-    out, joints, verts, loss = _fit_independent_frames(est, prev, xyz[1:], conf[1:], model_indices, _process_group())
-    return results + _batched_results(est, out, joints, verts, loss, prev, T - 1)
+    out, joints, vertex_of, loss = _fit_independent_frames(est, prev, xyz, conf, model_indices, _process_group(),
+                                                           gather_vertices)
+    return [BodyModelFitResult(params=est.fitter.result_params(out, prev, slice(i, i + 1)), vertices=vertex_of(i),
+                               joints=joints[i: i + 1], loss=loss[i]) for i in range(T)]
 
 
 def _batched_results(est, out, joints, verts, loss, init, n) -> list[BodyModelFitResult]:

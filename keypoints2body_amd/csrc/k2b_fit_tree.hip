@@ -384,12 +384,9 @@ hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream) {
     hipError_t e;
 #define K2B_TREE(NS_, CH_)                                                                                             \
     do {                                                                                                               \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
-            e = hipFuncSetAttribute((const void*)k2b_fit_tree_kernel<NS_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e;                                                                             \
-            attr_set = true;                                                                                           \
-        }                                                                                                              \
+        static std::atomic<unsigned long long> lds_set{0};                                                             \
+        e = ensure_dynamic_lds(k2b_fit_tree_kernel<NS_, CH_>, lds_set, lds);                                    \
+        if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL((k2b_fit_tree_kernel<NS_, CH_>), grid, block, lds, stream, a);                              \
     } while (0)
     const bool chain = a.chain_len > 1;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "k2b_device.h"
 
 namespace k2b {
@@ -207,6 +209,20 @@ struct VertexTermArgs {
 hipError_t launch_vertex_term(const VertexTermArgs& a, hipStream_t stream);
 hipError_t launch_adam(float* x, const float* g, float* m, float* v, long long n, float lr_over_bc1, float sqrt_bc2,
                        float one_minus_beta1, float beta2, float one_minus_beta2, float eps, hipStream_t stream);
+
+// Raises a kernel's dynamic-LDS limit once PER DEVICE (the attribute is per device; a process-wide flag left the second
+// GPU of a process without it, and two threads raced on it): one atomic flag per device ordinal and kernel instantiation.
+template <class Kernel>
+inline hipError_t ensure_dynamic_lds(Kernel kernel, std::atomic<unsigned long long>& done_mask, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);   // idempotent: a race repeats it
+    if (e == hipSuccess) done_mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // Geodesic angle (degrees) between n pairs of axis-angle rotations (evaluation metric, k2b_metrics.hip).
 hipError_t launch_angular_error(const float* pred, const float* gt, float* out, long long n, hipStream_t stream);

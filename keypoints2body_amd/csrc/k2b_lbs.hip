@@ -872,12 +872,9 @@ hipError_t launch_skin_tiles(const TileArgs& a_in, int num_cus, hipStream_t stre
     hipError_t e = hipSuccess;
 #define K2B_TILE(GA_, EPS_)                                                                                          \
     do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            e = hipFuncSetAttribute((const void*)k2b_lbs_tile_kernel<GA_, EPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e;                                                                           \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
+        static std::atomic<unsigned long long> lds_set{0};                                                             \
+        e = ensure_dynamic_lds(k2b_lbs_tile_kernel<GA_, EPS_>, lds_set, lds);                                    \
+        if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL((k2b_lbs_tile_kernel<GA_, EPS_>), dim3(wgs), dim3(512), lds, stream, a);                  \
     } while (0)
     if (GA == 3) K2B_TILE(3, 12);

@@ -37,7 +37,7 @@ class BodyModel:
     NUM_HAND_JOINTS = 15
 
     def __init__(self, v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents,
-                 extra_vertex_ids=None, device=None, model_type: str = "smpl"):
+                 extra_vertex_ids=None, device=None, model_type: str = "smpl", num_betas: Optional[int] = None):
         self.native = native.NativeModel(v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents,
                                          extra_vertex_ids, device=device)
         self.device = self.native.device
@@ -49,7 +49,13 @@ class BodyModel:
         self.num_expression_coeffs = 0
         if self.packed:
             self.NUM_BODY_JOINTS = 21
-            self.num_betas = 10 if self.num_shape > 10 else self.num_shape
+            # `shapedirs` = betas | expression: the split is the caller's (smplx: num_betas / num_expression_coeffs of the
+            # module); without one, smplx's defaults (10 betas, the rest expression)
+            if num_betas is None:
+                num_betas = 10 if self.num_shape > 10 else self.num_shape
+            if not 1 <= int(num_betas) <= self.num_shape:
+                raise ValueError(f"num_betas={num_betas} outside [1, {self.num_shape}]")
+            self.num_betas = int(num_betas)
             self.num_expression_coeffs = self.num_shape - self.num_betas
         else:
             self.num_betas = self.num_shape
@@ -115,18 +121,11 @@ class BodyModel:
 
     @classmethod
     def from_smplx(cls, model, device=None) -> "BodyModel":
-        """Take the constants of a loaded ``smplx`` SMPL module (or any object exposing
-        ``v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents`` and,
-        optionally, ``vertex_joint_selector.extra_joints_idxs``)."""
-        get = lambda name: getattr(model, name)
-        selector = getattr(model, "vertex_joint_selector", None)
-        extra = getattr(selector, "extra_joints_idxs", None) if selector is not None else None
-        if extra is None:
-            extra = getattr(model, "extra_vertex_ids", None)
-        nb = int(getattr(model, "num_betas", get("shapedirs").shape[2]))
-        shapedirs = get("shapedirs")[:, :, :nb]
-        return cls(get("v_template"), shapedirs, get("posedirs"), get("J_regressor"), get("lbs_weights"),
-                   get("parents"), extra, device=device)
+        """Take the constants of a loaded ``smplx`` module (or any object exposing
+        ``v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents`` and, optionally, ``expr_dirs``,
+        ``num_betas``, ``num_expression_coeffs``, ``pose_mean``, ``vertex_joint_selector.extra_joints_idxs``): see
+        ``smplx_constants`` for the conventions."""
+        return cls(**smplx_constants(model), device=device)
 
     @classmethod
     def from_npz(cls, path: str, device=None) -> "BodyModel":
@@ -168,6 +167,50 @@ class BodyModel:
                                full_pose=torch.cat((go, bp), dim=1) if return_full_pose else None)
 
     forward = __call__
+
+
+def smplx_constants(model) -> dict:
+    """Constructor arguments of ``BodyModel`` from an smplx-style module (pure attribute reading: no device needed).
+
+    Conventions, as smplx (>= 0.1.28, the reference's pin) lays its buffers out - PARITY UNPINNED at that boundary (smplx is
+    not installed here; covered by a stub object in ``tests/test_host_logic.py``):
+
+    * ``shapedirs`` holds the betas' directions (``[:, :, :num_betas]``); SMPL-X keeps the expression directions in a SEPARATE
+      buffer ``expr_dirs`` (V, 3, num_expression_coeffs): they are concatenated behind the betas, so the kernels see one
+      shape vector betas | expression and ``num_betas`` records the split (16-beta SMPL-H keeps all 16);
+    * hands are full axis-angle poses (``use_pca=False``); a module built with ``use_pca=True`` has 6-12 PCA coefficients per
+      hand, which this engine does not take (the packed pose has 45 values per hand);
+    * ``pose_mean`` (smplx adds it to the full pose before Rodrigues; non-zero for ``flat_hand_mean=False``, the smplx default)
+      would make a zero hand pose mean a different mesh than here: a non-zero one is refused - build the smplx module with
+      ``flat_hand_mean=True``.
+    """
+    get = lambda name: getattr(model, name)
+    selector = getattr(model, "vertex_joint_selector", None)
+    extra = getattr(selector, "extra_joints_idxs", None) if selector is not None else None
+    if extra is None:
+        extra = getattr(model, "extra_vertex_ids", None)
+    host = lambda x: np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x)
+    shapedirs = host(get("shapedirs"))
+    nb = int(getattr(model, "num_betas", shapedirs.shape[2]))
+    nb = min(nb, shapedirs.shape[2])
+    shapedirs = shapedirs[:, :, :nb]
+    expr = getattr(model, "expr_dirs", None)
+    if expr is not None:
+        expr = host(expr)
+        ne = int(getattr(model, "num_expression_coeffs", expr.shape[2]))
+        shapedirs = np.concatenate([shapedirs, expr[:, :, :min(ne, expr.shape[2])]], axis=2)
+    if bool(getattr(model, "use_pca", False)):
+        raise NotImplementedError("an smplx module with use_pca=True (PCA hand coefficients): build it with use_pca=False, "
+                                  "this engine fits full axis-angle hand poses")
+    pose_mean = getattr(model, "pose_mean", None)
+    if pose_mean is not None and float(np.abs(host(pose_mean)).max()) > 0.0:
+        raise NotImplementedError("an smplx module with a non-zero pose_mean (flat_hand_mean=False): build it with "
+                                  "flat_hand_mean=True - the kernels apply the pose as given")
+    nj = int(host(get("parents")).shape[0])
+    return dict(v_template=host(get("v_template")), shapedirs=np.ascontiguousarray(shapedirs), posedirs=host(get("posedirs")),
+                J_regressor=host(get("J_regressor")), lbs_weights=host(get("lbs_weights")), parents=host(get("parents")),
+                extra_vertex_ids=None if extra is None else host(extra),
+                model_type="smplx" if nj == 55 else ("smplh" if nj == 52 else "smpl"), num_betas=nb)
 
 
 def as_body_model(model, device=None) -> BodyModel:

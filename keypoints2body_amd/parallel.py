@@ -70,6 +70,74 @@ def gather_fit_outputs(out: Dict[str, torch.Tensor], dist=None, pad_to: Optional
     return (gathered, work) if async_op else gathered
 
 
+def _world(dist) -> Tuple[int, int]:
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1, 0
+    return dist.get_world_size(), dist.get_rank()
+
+
+def gather_rows(t: torch.Tensor, dist, pad_to: int, async_op: bool = False):
+    """All-gather of one per-frame tensor (rows = this rank's frames, zero-padded to `pad_to` rows so that uneven and
+    empty shards take part): returns ``(world * pad_to, ...)`` on every rank, and the work handle with ``async_op``."""
+    rows = t.shape[0]
+    if rows != pad_to:
+        padded = t.new_zeros((pad_to,) + tuple(t.shape[1:]))
+        padded[:rows] = t
+        t = padded
+    t = t.contiguous()
+    gathered = t.new_empty((dist.get_world_size() * pad_to,) + tuple(t.shape[1:]))
+    work = dist.all_gather_into_tensor(gathered, t, async_op=async_op)
+    return (gathered, work) if async_op else gathered
+
+
+def valid_rows(num_frames: int, world: int, device=None) -> torch.Tensor:
+    """Indices of the real frames inside a gathered ``(world * ceil(T / world), ...)`` tensor (padding rows dropped)."""
+    per = (num_frames + world - 1) // world
+    idx = [torch.arange(r * per, r * per + (shard_bounds(num_frames, world, r)[1] - shard_bounds(num_frames, world, r)[0]))
+           for r in range(world)]
+    return torch.cat(idx).to(device) if idx else torch.zeros((0,), dtype=torch.long, device=device)
+
+
+def fit_forward_exchange(fit_fn: Callable[[], Dict[str, torch.Tensor]], forward_fn, dist=None, pad_to: Optional[int] = None,
+                         gather_joints: bool = True, gather_vertices: bool = False) -> Dict[str, object]:
+    """ONE rank's share of a frame-sharded fit - what both ``optimize_params_sequence`` (independent frames under a process
+    group) and ``bench.py`` run per step, in the order that hides the exchange:
+
+      1. ``fit_fn()`` fits THIS rank's block (no communication during the Adam iterations);
+      2. the all-gather of the packed parameters + per-frame loss (344 B/frame for SMPL) is only ENQUEUED - RCCL runs it on
+         its own stream behind the fit kernel;
+      3. ``forward_fn(out)`` = the final forward over the rank's OWN block only (joints + vertices stay sharded);
+      4. the joints of the block (540 B/frame) are all-gathered; the vertices (82.7 KB/frame) only with ``gather_vertices``
+         (a second, separately reported exchange: SURVEY §8e), otherwise every rank keeps the vertices of its own block;
+      5. wait for the collectives (stream-ordered: the host is not blocked).
+
+    `pad_to` = rows every rank contributes (ceil(T / world); shards may be short or empty).  Returns a dict: ``local``
+    (this rank's fit outputs), ``packed`` (world * pad_to, P + 1) or None for one rank, ``joints`` (gathered, or local),
+    ``vertices`` (local block, or gathered), ``vertices_gathered``.
+    """
+    out = fit_fn()
+    world, _ = _world(dist)
+    if world == 1:
+        joints, verts = forward_fn(out)
+        return {"local": out, "packed": None, "joints": joints, "vertices": verts, "vertices_gathered": True}
+    rows = pad_to if pad_to is not None else out["loss"].shape[0]
+    packed, work = gather_fit_outputs(out, dist, pad_to=rows, async_op=True)
+    joints, verts = forward_fn(out)
+    works = [work]
+    if gather_joints and joints is not None:
+        joints, w = gather_rows(joints, dist, rows, async_op=True)
+        works.append(w)
+    gathered_v = False
+    if gather_vertices and verts is not None:
+        verts, w = gather_rows(verts, dist, rows, async_op=True)
+        works.append(w)
+        gathered_v = True
+    for w in works:
+        if w is not None:
+            w.wait()
+    return {"local": out, "packed": packed, "joints": joints, "vertices": verts, "vertices_gathered": gathered_v}
+
+
 def fit_frames_sharded(fit_fn: Callable[[slice], Dict[str, torch.Tensor]], num_frames: int, num_betas: int,
                        pose_dim: int, dist=None) -> Dict[str, torch.Tensor]:
     """Fit `num_frames` independent frames across all ranks and return the concatenated
@@ -78,18 +146,13 @@ def fit_frames_sharded(fit_fn: Callable[[slice], Dict[str, torch.Tensor]], num_f
     `fit_fn(frame_slice)` fits this rank's block and returns the usual dict of (b, .)
     tensors; on the GPUs it wraps ``WorldSpaceFitter.fit_batch``.  Frame order is preserved.
     """
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    world, rank = _world(dist)
     start, stop = shard_bounds(num_frames, world, rank)
     per = (num_frames + world - 1) // world
     out = fit_fn(slice(start, stop))
     gathered = gather_fit_outputs(out, dist if world > 1 else None, pad_to=per)
     if world > 1:
-        # drop the padding rows of short / empty trailing shards
-        keep = torch.cat([torch.arange(r * per, r * per + (shard_bounds(num_frames, world, r)[1]
-                                                            - shard_bounds(num_frames, world, r)[0]))
-                          for r in range(world)]).to(gathered.device)
-        gathered = gathered.index_select(0, keep)
+        gathered = gathered.index_select(0, valid_rows(num_frames, world, gathered.device))   # drop the padding rows
     return unpack_outputs(gathered, num_betas, pose_dim)
 
 

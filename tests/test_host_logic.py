@@ -145,3 +145,36 @@ def test_mano_and_flame_requests_are_rejected_before_anything_is_loaded():
         common.check_request(FrameOptimizeConfig(), name)
     with pytest.raises(ValueError):
         common.check_request(FrameOptimizeConfig(), "nope")
+
+
+def test_smplx_module_constants_are_adopted_with_expression_and_beta_split():
+    """an smplx SMPLX module keeps the expression directions in ``expr_dirs``; the betas / expression split is
+    the module's; a non-zero ``pose_mean`` (flat_hand_mean=False) or PCA hands are refused.  Stub object, no smplx needed."""
+    from types import SimpleNamespace
+
+    import pytest
+
+    from keypoints2body_amd.models.body_model import smplx_constants
+    V, J = 40, 55
+    rng = np.random.default_rng(0)
+    f = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32)
+    stub = SimpleNamespace(v_template=f(V, 3), shapedirs=f(V, 3, 16), expr_dirs=f(V, 3, 10), posedirs=f(9 * (J - 1), 3 * V),
+                           J_regressor=f(J, V), lbs_weights=f(V, J), parents=torch.arange(-1, J - 1), num_betas=16,
+                           num_expression_coeffs=10, pose_mean=torch.zeros(3 * J), use_pca=False,
+                           vertex_joint_selector=SimpleNamespace(extra_joints_idxs=torch.tensor([1, 2, 3])))
+    c = smplx_constants(stub)
+    assert c["shapedirs"].shape == (V, 3, 26) and c["num_betas"] == 16 and c["model_type"] == "smplx"
+    assert np.array_equal(c["shapedirs"][:, :, 16:], stub.expr_dirs.numpy()) and list(c["extra_vertex_ids"]) == [1, 2, 3]
+    stub.num_betas = 10                                   # fewer betas than the file holds: smplx slices, so does this
+    assert smplx_constants(stub)["shapedirs"].shape == (V, 3, 20)
+    stub.pose_mean = torch.full((3 * J,), 0.1)
+    with pytest.raises(NotImplementedError, match="flat_hand_mean"):
+        smplx_constants(stub)
+    stub.pose_mean, stub.use_pca = None, True
+    with pytest.raises(NotImplementedError, match="use_pca"):
+        smplx_constants(stub)
+    # a plain SMPL module: no expr_dirs, every beta kept
+    smpl = SimpleNamespace(v_template=f(V, 3), shapedirs=f(V, 3, 10), posedirs=f(207, 3 * V), J_regressor=f(24, V),
+                           lbs_weights=f(V, 24), parents=torch.arange(-1, 23))
+    c = smplx_constants(smpl)
+    assert c["shapedirs"].shape == (V, 3, 10) and c["model_type"] == "smpl" and c["extra_vertex_ids"] is None

@@ -1,14 +1,18 @@
 """The PUBLIC ``optimize_params_sequence`` under an initialised process group (two gloo ranks on CPU):
-with ``use_previous_frame_init=False`` frames 1..T-1 must be sharded over the ranks and every rank must
-return the full list, equal to the single-process result in frame order.
+with ``use_previous_frame_init=False`` the T frames must be cut into one contiguous block per rank, every rank must
+fit AND forward only its own block (frame 0 once, on the rank that owns it), and every rank must return
+parameters, joints and loss of all frames - vertices of its own block only unless ``gather_vertices=True``.
 
 The HIP engine cannot run here, so (tests being allowed to) the oracle stands in for the kernel behind
-the engine seam: a stand-in ``OptimizeEngine`` whose estimator runs ``oracle.fit_torch.fit_world_adam``.
-Everything above that seam - normalisation, the frame-0 / frames-1.. split, the sharding, the gather and
-the assembly of results - is the product code of ``keypoints2body_amd/api/sequence.py``.
+the engine seam: a stand-in ``OptimizeEngine`` whose estimator runs ``oracle.fit_torch.fit_world_adam``
+(SMPL) or ``fit_world_adam_smplx`` (a packed 55-joint model: 162 pose values, betas | expression = 20, non-zero
+hand start).  Everything above that seam - normalisation, the frame-0 / frames-1.. split, the sharding, the
+exchange and the assembly of results - is the product code of ``keypoints2body_amd/api/sequence.py`` and
+``keypoints2body_amd/parallel.py``.
 """
 import os
 import socket
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -17,75 +21,112 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 T_FRAMES = 6
-CALLS = []          # (rank-local) sizes of the batched fits the stand-in estimator was asked for
+CALLS = []          # (rank-local) (seq_ind, frames) of the batched fits the stand-in estimator was asked for
+FORWARDS = []       # (rank-local) frames of every final forward
+
+X_POSE = (("body_pose", 63), ("jaw_pose", 3), ("leye_pose", 3), ("reye_pose", 3), ("left_hand_pose", 45), ("right_hand_pose", 45))
 
 
 class _Fitter:
-    def __init__(self, model):
+    def __init__(self, model, packed):
         self.model = model
+        if packed:
+            self.smpl = SimpleNamespace(packed=True, num_joints=55, num_shape=20)
 
     def fit_batch(self, *a, **k):       # presence selects the batched branch of the sequence API
         raise AssertionError("reached through the estimator")
 
+    def _kwargs(self, out):
+        if not hasattr(self, "smpl"):
+            return dict(global_orient=out["global_orient"], body_pose=out["body_pose"], betas=out["betas"], transl=out["transl"])
+        kw, o = dict(global_orient=out["global_orient"], transl=out["transl"], betas=out["betas"][:, :10],
+                     expression=out["betas"][:, 10:]), 0
+        for name, cols in X_POSE:
+            kw[name] = out["body_pose"][:, o:o + cols]
+            o += cols
+        return kw
+
     def final_forward(self, out, want_vertices=True):
+        FORWARDS.append(int(out["loss"].shape[0]))
         with torch.no_grad():
-            o = self.model(global_orient=out["global_orient"], body_pose=out["body_pose"], betas=out["betas"],
-                           transl=out["transl"])
+            o = self.model(**self._kwargs(out))
         return o.joints, o.vertices
 
     def result_params(self, out, init, rows=None):
-        from keypoints2body_amd.models.smpl_data import SMPLData
+        from keypoints2body_amd.models.smpl_data import SMPLData, SMPLXData
         sl = slice(None) if rows is None else rows
-        return SMPLData(betas=out["betas"][sl], global_orient=out["global_orient"][sl], body_pose=out["body_pose"][sl],
-                        transl=out["transl"][sl])
+        out = {k: v[sl] for k, v in out.items()}
+        if not hasattr(self, "smpl"):
+            return SMPLData(betas=out["betas"], global_orient=out["global_orient"], body_pose=out["body_pose"], transl=out["transl"])
+        kw = self._kwargs(out)
+        return SMPLXData(**kw)
 
 
 class _Estimator:
-    def __init__(self, model, prior, cfg):
-        self.model, self.prior, self.cfg = model, prior, cfg
-        self.fitter = _Fitter(model)
+    def __init__(self, model, prior, cfg, packed=False):
+        self.model, self.prior, self.cfg, self.packed = model, prior, cfg, packed
+        self.fitter = _Fitter(model, packed)
 
     def _fit(self, init, j3d, conf, seq_ind):
-        from oracle.fit_torch import fit_world_adam
+        from oracle.fit_torch import fit_world_adam, fit_world_adam_smplx
         iters = self.cfg.num_iters_first if seq_ind == 0 else self.cfg.num_iters_followup
         n = j3d.shape[0]
         rep = lambda x: torch.as_tensor(x).expand(n, -1).contiguous()
         c = conf if conf is None or conf.dim() == 1 else conf[0]
-        return fit_world_adam(self.model, self.prior, rep(init.global_orient), rep(init.body_pose), rep(init.betas),
-                              rep(init.transl), j3d, c, num_iters=iters, seq_ind=seq_ind)
+        if not self.packed:
+            o = fit_world_adam(self.model, self.prior, rep(init.global_orient), rep(init.body_pose), rep(init.betas),
+                               rep(init.transl), j3d, c, num_iters=iters, seq_ind=seq_ind)
+            return {"global_orient": o.global_orient, "body_pose": o.body_pose, "betas": o.betas, "transl": o.transl,
+                    "loss": o.loss}, o.joints, o.vertices
+        from oracle.fit_torch import SMPLX_FIELDS
+        p = {k: rep(getattr(init, k)) for k in SMPLX_FIELDS}
+        fitted, loss, joints, verts, _ = fit_world_adam_smplx(self.model, self.prior, p, j3d, c, num_iters=iters, seq_ind=seq_ind,
+                                                              model_idx=list(range(j3d.shape[1])))
+        out = {"global_orient": fitted["global_orient"], "transl": fitted["transl"],
+               "body_pose": torch.cat([fitted[k] for k, _ in X_POSE], dim=1),
+               "betas": torch.cat([fitted["betas"], fitted["expression"]], dim=1), "loss": loss}
+        return out, joints, verts
 
     def fit_batch(self, init, j3d, conf, seq_ind, target_model_indices=None, per_frame_conf=False, run_forward=True):
-        CALLS.append(int(j3d.shape[0]))
-        o = self._fit(init, j3d, conf, seq_ind)
-        out = {"global_orient": o.global_orient, "body_pose": o.body_pose, "betas": o.betas, "transl": o.transl,
-               "loss": o.loss}
+        CALLS.append((int(seq_ind), int(j3d.shape[0])))
+        assert init.global_orient.shape[0] == j3d.shape[0]              # the start is repeated per frame, data class kept
+        out, joints, verts = self._fit(init, j3d, conf, seq_ind)
         if not run_forward:
-            return out, None, None, o.loss
-        return out, o.joints, o.vertices, o.loss
+            return out, None, None, out["loss"]
+        return out, joints, verts, out["loss"]
 
 
-class _Engine:
-    def __init__(self, model, frame_config, device=None, model_type="smpl", pose_prior=None):
-        self.estimator = _Estimator(model, pose_prior, frame_config)
-
-    def fit_frame(self, init_params, j3d, conf_3d, seq_ind, target_model_indices=None):
-        from keypoints2body_amd.models.smpl_data import BodyModelFitResult, SMPLData
-        o = self.estimator._fit(init_params, j3d, conf_3d, seq_ind)
-        return BodyModelFitResult(params=SMPLData(betas=o.betas, global_orient=o.global_orient, body_pose=o.body_pose,
-                                                  transl=o.transl), vertices=o.vertices, joints=o.joints,
-                                  loss=o.loss.sum())
+def _engine(packed):
+    class _Engine:
+        def __init__(self, model, frame_config, device=None, model_type="smpl", pose_prior=None):
+            self.estimator = _Estimator(model, pose_prior, frame_config, packed)
+    return _Engine
 
 
-def _run_public_api():
-    """optimize_params_sequence on the first T_FRAMES frames of a golden case, oracle behind the engine seam."""
+def _patch(packed):
     from keypoints2body_amd.api import common, sequence
+    common.resolve_device = lambda device: torch.device("cpu")
+    common.obtain_model = lambda model, body_model, device: model
+    sequence.OptimizeEngine = _engine(packed)
+    return sequence
+
+
+def _pack_results(res, fields):
+    rows = []
+    for r in res:
+        rows.append(np.concatenate([np.asarray(getattr(r.params, k)).ravel() for k in fields]
+                                   + [np.asarray(r.loss, dtype=np.float32).reshape(-1), r.joints.numpy().ravel()]))
+    verts = [None if r.vertices is None else r.vertices.numpy().ravel()[:300] for r in res]
+    return np.stack(rows), verts
+
+
+def _run_public_api(gather_vertices=False):
+    """optimize_params_sequence on the first T_FRAMES frames of a golden case, oracle behind the engine seam."""
     from keypoints2body_amd.core.config import FrameOptimizeConfig, SequenceOptimizeConfig
     from keypoints2body_amd.models.smpl_data import SMPLData
     from tests import helpers as H
 
-    common.resolve_device = lambda device: torch.device("cpu")
-    common.obtain_model = lambda model, body_model, device: model
-    sequence.OptimizeEngine = _Engine
+    sequence = _patch(False)
     d = H.load_case("amass_batched")
     j3d = torch.tensor(np.tile(d["j3d"], (3, 1, 1))[:T_FRAMES])
     j3d = j3d + 0.01 * torch.arange(T_FRAMES).view(-1, 1, 1)            # distinct frames
@@ -97,12 +138,41 @@ def _run_public_api():
         use_previous_frame_init=False, use_shape_optimization=False)
     res = sequence.optimize_params_sequence(j3d, init_params=init, body_model="smpl", joint_layout="AMASS",
                                             model=H.oracle_model(), config=cfg, pose_prior=H.oracle_prior(),
-                                            mean_params=(torch.zeros(1, 72), torch.zeros(1, 10)))
-    pack = lambda r: np.concatenate([r.params.global_orient.numpy().ravel(), r.params.body_pose.numpy().ravel(),
-                                     r.params.betas.numpy().ravel(), r.params.transl.numpy().ravel(),
-                                     np.asarray(r.loss, dtype=np.float32).reshape(-1),
-                                     r.joints.numpy().ravel(), r.vertices.numpy().ravel()[:300]])
-    return np.stack([pack(r) for r in res])
+                                            mean_params=(torch.zeros(1, 72), torch.zeros(1, 10)),
+                                            gather_vertices=gather_vertices)
+    return _pack_results(res, ("global_orient", "body_pose", "betas", "transl"))
+
+
+X_FIELDS = ("global_orient", "body_pose", "jaw_pose", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose", "betas",
+            "expression", "transl")
+
+
+def _run_public_api_smplx(T=4):
+    """The same through a packed 55-joint model: 189-column exchange, ``SMPLXData`` start with NON-ZERO hands / jaw /
+    expression that every frame must start from."""
+    from keypoints2body_amd.core.config import FrameOptimizeConfig, SequenceOptimizeConfig
+    from keypoints2body_amd.models.smpl_data import SMPLXData
+    from keypoints2body_amd import synthetic
+    from tests import helpers as H
+
+    sequence = _patch(True)
+    model = H.oracle_model_x()
+    poses = synthetic.make_poses_x(T, seed=3)
+    tt = lambda a: torch.tensor(np.ascontiguousarray(a))
+    with torch.no_grad():
+        j3d = model(**{k: tt(getattr(poses, k)) for k in X_FIELDS}).joints[:, :22].clone()
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda c, s: s * torch.randn(1, c, generator=g)
+    init = SMPLXData(betas=torch.zeros(1, 10), global_orient=torch.zeros(1, 3), body_pose=torch.zeros(1, 63),
+                     transl=j3d[:1, 0].clone(), left_hand_pose=rnd(45, 0.1), right_hand_pose=rnd(45, 0.1),
+                     expression=rnd(10, 0.3), jaw_pose=rnd(3, 0.1), leye_pose=torch.zeros(1, 3), reye_pose=torch.zeros(1, 3))
+    cfg = SequenceOptimizeConfig(
+        frame=FrameOptimizeConfig(use_lbfgs=False, num_iters_first=2, num_iters_followup=2, joints_category="AMASS"),
+        use_previous_frame_init=False, use_shape_optimization=False, fix_foot=False)
+    res = sequence.optimize_params_sequence(j3d, init_params=init, body_model="smplx", joint_layout="AMASS",
+                                            model=model, config=cfg, pose_prior=H.oracle_prior(),
+                                            mean_params=(torch.zeros(1, 66), torch.zeros(1, 10)))
+    return _pack_results(res, X_FIELDS), init
 
 
 def _free_port():
@@ -111,39 +181,78 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, which):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        got = _run_public_api()
-        q.put((rank, got, list(CALLS)))
+        if which == "smplx":
+            (arr, verts), _ = _run_public_api_smplx()
+        else:
+            arr, verts = _run_public_api(gather_vertices=(which == "gather"))
+        q.put((rank, arr, verts, list(CALLS), list(FORWARDS)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_public_sequence_api_shards_independent_frames_over_two_ranks():
-    torch.set_num_threads(2)
-    CALLS.clear()
-    single = _run_public_api()
-    assert single.shape[0] == T_FRAMES and CALLS == [T_FRAMES - 1]       # one batched fit of frames 1..T-1
+def _two_ranks(which):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, which)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
     for _ in procs:
-        rank, arr, calls = q.get(timeout=500)
-        got[rank] = (arr, calls)
+        rank, arr, verts, calls, fwd = q.get(timeout=500)
+        got[rank] = (arr, verts, calls, fwd)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    # 5 remaining frames over 2 ranks: blocks of 3 and 2, each rank fitted only its own block
-    assert got[0][1] == [3] and got[1][1] == [2]
+    return got
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("which", ["local", "gather"])
+def test_public_sequence_api_shards_independent_frames_over_two_ranks(which):
+    torch.set_num_threads(2)
+    del CALLS[:], FORWARDS[:]
+    single, single_v = _run_public_api()
+    # one process: frame 0 (first-frame semantics), frames 1..T-1 as one batch, ONE forward over everything
+    assert single.shape[0] == T_FRAMES and CALLS == [(0, 1), (1, T_FRAMES - 1)] and FORWARDS == [T_FRAMES]
+    assert all(v is not None for v in single_v)
+    got = _two_ranks(which)
+    # 6 frames over 2 ranks: blocks [0, 3) and [3, 6); frame 0 is fitted by rank 0 only; each rank forwards ITS 3 frames
+    assert got[0][2] == [(0, 1), (1, 2)] and got[1][2] == [(1, 3)]
+    assert got[0][3] == [3] and got[1][3] == [3]
+    for rank in (0, 1):
+        arr, verts = got[rank][0], got[rank][1]
+        assert arr.shape == single.shape
+        assert np.abs(arr - single).max() < 5e-6, rank                   # parameters, loss and joints of ALL frames
+        own = range(0, 3) if rank == 0 else range(3, 6)
+        for i in range(T_FRAMES):
+            if which == "gather" or i in own:
+                assert np.abs(verts[i] - single_v[i]).max() < 5e-6
+            else:
+                assert verts[i] is None                                  # vertices stay sharded by default
+    assert np.array_equal(got[0][0], got[1][0])                          # gathered results: same bits on every rank
+
+
+@pytest.mark.timeout(600)
+def test_public_sequence_api_shards_a_packed_smplx_model():
+    """the exchange must take its widths from the fitter (162 / 20 columns for a packed 55-joint model, not the
+    63 / 10 of the ``SMPLXData`` start), and every frame must start from the FULL start (hands, jaw, expression)."""
+    torch.set_num_threads(2)
+    del CALLS[:], FORWARDS[:]
+    (single, single_v), init = _run_public_api_smplx()
+    assert single.shape[0] == 4 and CALLS == [(0, 1), (1, 3)]
+    # two iterations of Adam move every value by <= 0.02: fitted hands stay near their NON-ZERO start in every frame
+    cols = np.cumsum([0] + [3, 63, 3, 3, 3, 45, 45, 10, 10, 3])
+    lh = single[:, cols[5]:cols[6]]
+    assert np.abs(lh - init.left_hand_pose.numpy()).max() < 0.05 and np.abs(init.left_hand_pose.numpy()).max() > 0.1
+    got = _two_ranks("smplx")
+    assert got[0][2] == [(0, 1), (1, 1)] and got[1][2] == [(1, 2)]
     for rank in (0, 1):
         assert got[rank][0].shape == single.shape
         assert np.abs(got[rank][0] - single).max() < 5e-6, rank
-    assert np.array_equal(got[0][0][:, :85], got[1][0][:, :85])          # gathered parameters: same bits on every rank
+    assert np.array_equal(got[0][0], got[1][0])
