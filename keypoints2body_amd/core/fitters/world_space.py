@@ -16,7 +16,8 @@ host (one upload of the parameters and one download of [gradient | loss] per clo
 parameters it is given: the reference hands ONE optimiser the parameters of the whole batch, so for
 B > 1 its frames share a line search (a batch is then NOT B independent fits); the API only ever
 calls it with B = 1 (``api/sequence.py:215``).  This class runs one L-BFGS per frame, which equals
-the reference for B = 1 and deliberately differs (independent frames) for B > 1.
+the reference for B = 1 and deliberately differs (independent frames) for B > 1 - and for B > 1 the per-frame optimisers
+advance in lock-step (``core/lbfgs_batched.py``) so that one launch per round serves every frame.
 
 Differences, all deliberate and documented in DESIGN.md:
 
@@ -249,6 +250,8 @@ class WorldSpaceFitter:
         B, D = go.shape[0], bp.shape[1]
         NB = be.shape[1]
         preserve = bp.clone()                          # world_space.py:159
+        if B > 1:
+            return self._fit_lbfgs_lockstep(cfg, max_iter, model_idx, tgt, conf, go, bp, be, tr, preserve, freeze_betas)
         outs = {k: [] for k in ("global_orient", "body_pose", "betas", "transl", "loss")}
         # The optimiser's own arithmetic (two-loop recursion, strong-Wolfe bookkeeping: hundreds of tiny tensor operations per
         # iteration) runs on HOST tensors, as it does in the reference (whose default device is the CPU): on device tensors every
@@ -296,6 +299,43 @@ class WorldSpaceFitter:
             outs["global_orient"].append(p[0].detach().to(dev)); outs["body_pose"].append(p[1].detach().to(dev))
             outs["transl"].append(p[2].detach().to(dev)); outs["betas"].append(beta.detach().to(dev)); outs["loss"].append(final_loss)
         return {k: torch.cat(v, dim=0).contiguous() for k, v in outs.items()}
+
+    def _fit_lbfgs_lockstep(self, cfg, max_iter, model_idx, tgt, conf, go, bp, be, tr, preserve, freeze_betas):
+        """B > 1 frames in the L-BFGS branch: the B per-frame optimisers advance in lock-step (``core/lbfgs_batched.py``, torch's
+        L-BFGS / strong-Wolfe restated and vectorised over the frames), so ONE evaluate-only launch over all B frames serves
+        the pending closure call of every frame - ~max_iter * 5 / 4 launches for the whole batch instead of that many per
+        frame, and the optimiser's bookkeeping is a few numpy operations per round instead of B x hundreds of tiny tensor
+        operations.  Frames stay independent (each has its own history, line search and stopping rule).  Per round: one
+        upload of the (B, P) points, one launch, one download of [gradient | loss]."""
+        from ..lbfgs_batched import BatchedLBFGS
+        B, D, NB = go.shape[0], bp.shape[1], be.shape[1]
+        dev = self.device
+        shape_in_optimiser = not freeze_betas or self.smpl.packed          # as in the per-frame path below
+        start = torch.cat((go, bp, be, tr), dim=1)                         # kernel layout [go | pose | shape | transl]
+        free = np.ones(3 + D + NB + 3, dtype=bool)
+        if not shape_in_optimiser:
+            free[3 + D: 3 + D + NB] = False
+        free_t = torch.as_tensor(free, device=dev)
+        flat = start.clone()
+
+        def launch(x_free, want_grad):
+            with torch.no_grad():
+                flat[:, free_t] = torch.from_numpy(np.ascontiguousarray(x_free, dtype=np.float32)).to(dev)
+                cur = (flat[:, 0:3].contiguous(), flat[:, 3:3 + D].contiguous(), flat[:, 3 + D:3 + D + NB].contiguous(),
+                       flat[:, 3 + D + NB:].contiguous())
+                return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, *cur,
+                                        preserve_pose=preserve, want_grad=want_grad), cur
+
+        def evaluate(x_free):
+            r, _ = launch(x_free, True)
+            back = torch.cat((r["grad"], r["loss"][:, None]), dim=1).cpu().numpy()
+            return back[:, -1].astype(np.float64), back[:, :-1][:, free]
+
+        opt = BatchedLBFGS(evaluate, start.cpu().numpy()[:, free], lr=float(self.step_size), max_iter=max_iter)
+        x = opt.run()
+        r, cur = launch(x, False)                                          # final loss re-evaluated (world_space.py:245-246)
+        self.last_lbfgs_rounds = opt.rounds
+        return {"global_orient": cur[0], "body_pose": cur[1], "betas": cur[2], "transl": cur[3], "loss": r["loss"]}
 
     def fit_frame(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
                   seq_ind: int = 0, target_model_indices: Optional[torch.Tensor] = None,

@@ -1,0 +1,102 @@
+"""ORACLE TOOLING: golden vectors of the reference's SEQUENCE LOOP on real motion.
+
+Runs only in the build container (``/root/reference`` does not exist on the GPU box).  It drives the REAL reference
+``WorldSpaceFitter`` (reference ``keypoints2body/core/fitters/world_space.py``) in the order of the reference's own frame
+loop (``keypoints2body/api/sequence.py:120-128, 214-281``):
+
+* inputs: the first ``T`` frames of the two AMASS-layout joint sequences the reference ships as demo data
+  (``data/demo/test_motion1.npy`` (195, 22, 3) float64, ``test_motion2.npy`` (116, 22, 3) float32) - real motion, used as
+  INPUT data only (the fixtures store those frames as float32 arrays; no reference source text);
+* ``fix_foot``: confidences of joints 7, 8, 10, 11 set to 1.5 (``api/sequence.py:124-128``), per-frame ``conf[idx]``;
+* ``prev`` = the zero mean pose / shape with the root-aligned translation of frame 0 (``core/engine.py:110-128`` via the
+  reference's ``guess_init_transl_from_root``; the h5 mean-parameter file is a licensed asset that is absent here);
+* the loop: ``res = fitter.fit_frame(init_params=prev, j3d=frame, conf_3d=conf[idx], seq_ind=idx, ...)`` with the weights
+  ``OptimizationEstimator`` injects (``core/estimators/optimization.py:75-85``: 600 / 5 / freeze_betas False) and
+  ``prev = res.params`` (``api/sequence.py:280-281``) - so the preserve reference of frame t is the RESULT of frame t-1
+  (``world_space.py:159``), frame 0 runs ``num_iters_first`` iterations without the preserve term and every later frame
+  ``num_iters_followup`` with it (``world_space.py:211, 214``);
+* Adam branch (``use_lbfgs=False``), the config defaults 30 / 10 iterations (``core/config.py:32-33``) and the 100 / 50 of
+  ``smpl_fit.py``.
+
+The body model is the oracle's ``TorchSMPL`` over the synthetic constants (``model=`` plugin; smplx is absent), the mixture
+the synthetic ``gmm_08.pkl`` of ``gen_golden.py``.  Outputs: ``tests/golden/chain_motion{1,2}_*.npz``.
+
+Usage:  python oracle/gen_golden_chain.py
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO))
+
+from keypoints2body_amd import synthetic  # noqa: E402
+from oracle.gen_golden import GOLDEN, import_reference, sample_vertex_ids  # noqa: E402
+from oracle.smpl_torch import TorchSMPL  # noqa: E402
+
+DEMO = Path("/root/reference/data/demo")
+
+
+def run_chain(name, ref, model, frames, iters_first, iters_followup):
+    WorldSpaceFitter, guess_transl, _, SMPLData = ref
+    T = frames.shape[0]
+    xyz = torch.as_tensor(frames, dtype=torch.float32)
+    conf = torch.ones(T, 22)
+    conf[:, [7, 8, 10, 11]] = 1.5                                     # fix_foot (api/sequence.py:124-128)
+    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=iters_first, num_iters_followup=iters_followup,
+                              use_lbfgs=False, joints_category="AMASS", device=torch.device("cpu"))
+    pose, betas = torch.zeros(1, 72), torch.zeros(1, 10)
+    transl = guess_transl(model, pose, betas, xyz[0:1], joints_category="AMASS")
+    prev = SMPLData(betas=betas, global_orient=pose[:, :3].clone(), body_pose=pose[:, 3:].clone(), transl=transl)
+    init = prev
+    out = {k: [] for k in ("go", "bp", "be", "tr", "loss", "joints", "verts")}
+    vid = sample_vertex_ids(model.v_template.shape[0])
+    for idx in range(T):                                              # api/sequence.py:214-281
+        res = fitter.fit_frame(init_params=prev, j3d=xyz[idx: idx + 1], conf_3d=conf[idx], seq_ind=idx,
+                               target_model_indices=None, joint_loss_weight=600.0, pose_preserve_weight=5.0,
+                               freeze_betas=False)
+        p = res.params
+        out["go"].append(p.global_orient); out["bp"].append(p.body_pose); out["be"].append(p.betas); out["tr"].append(p.transl)
+        out["loss"].append(res.loss.reshape(1)); out["joints"].append(res.joints); out["verts"].append(res.vertices[:, vid])
+        prev = res.params
+    cat = lambda xs: torch.cat(xs, dim=0).detach().numpy()
+    np.savez_compressed(
+        GOLDEN / f"{name}.npz", case=name, num_iters_first=iters_first, num_iters_followup=iters_followup,
+        j3d=xyz.numpy(), conf=conf.numpy(),
+        init_global_orient=init.global_orient.numpy(), init_body_pose=init.body_pose.numpy(), init_betas=init.betas.numpy(),
+        init_transl=init.transl.numpy(),
+        out_global_orient=cat(out["go"]), out_body_pose=cat(out["bp"]), out_betas=cat(out["be"]), out_transl=cat(out["tr"]),
+        out_loss=cat(out["loss"]), out_joints=cat(out["joints"]), out_verts_sampled=cat(out["verts"]), sampled_vertex_ids=vid)
+    err = (torch.cat(out["joints"])[:, :22] - xyz).norm(dim=-1).mean()
+    print(f"[golden] {name}: T={T} iters {iters_first}/{iters_followup}, mean joint error {float(err) * 100:.2f} cm, "
+          f"losses {cat(out['loss'])[:3]} ...")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    consts = synthetic.make_body_model(seed=0)
+    model = TorchSMPL(consts)
+    gmm = synthetic.make_gmm(seed=0)
+    scratch = tempfile.mkdtemp(prefix="k2b_golden_chain_")
+    os.makedirs(os.path.join(scratch, "data", "models"))
+    with open(os.path.join(scratch, "data", "models", "gmm_08.pkl"), "wb") as f:
+        pickle.dump({"means": gmm.means, "covars": gmm.covars, "weights": gmm.weights}, f)
+    os.chdir(scratch)
+    ref = import_reference()
+    m1 = np.load(DEMO / "test_motion1.npy")
+    m2 = np.load(DEMO / "test_motion2.npy")
+    run_chain("chain_motion1_30_10", ref, model, m1[:20], 30, 10)
+    run_chain("chain_motion2_30_10", ref, model, m2[:20], 30, 10)
+    run_chain("chain_motion1_100_50", ref, model, m1[40:52], 100, 50)      # smpl_fit.py's counts, a later stretch of the motion
+
+
+if __name__ == "__main__":
+    main()

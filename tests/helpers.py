@@ -137,3 +137,12 @@ def native_fit(d, num_iters=None, want_grad=False, rows=None, shape="auto"):
     return native.fit_world(native_model(), native_prior(), cfg, case_indices(d), cuda(d["j3d"][sl]), conf,
                             cuda(d["init_global_orient"][sl]), cuda(d["init_body_pose"][sl]),
                             cuda(d["init_betas"][sl]), cuda(d["init_transl"][sl]), want_grad=want_grad)
+
+
+CHAIN_CASES = ("chain_motion1_30_10", "chain_motion2_30_10", "chain_motion1_100_50")
+
+
+def load_chain_case(name: str):
+    """Sequence-loop golden of ``oracle/gen_golden_chain.py``: the REAL reference fitter walked through its own frame
+    loop (api/sequence.py:214-281: fix_foot confidences, seq_ind = idx, prev = res.params) over real demo motion."""
+    return dict(np.load(GOLDEN / f"{name}.npz"))

@@ -334,6 +334,61 @@ def test_lbfgs_world_fit_matches_reference_golden(assets, case):
             assert torch.equal(res.params.betas.cpu(), t("init_betas"))
 
 
+@pytest.mark.parametrize("case", ["first", "followup", "frozen"])
+def test_lbfgs_lockstep_batch_matches_reference_golden(assets, case):
+    """B > 1 frames in the L-BFGS branch run as lock-step state machines (``core/lbfgs_batched.py``): ONE evaluate-only launch
+    per round for the whole batch.  Same statistical gate as the per-frame path above, with the five perturbed runs of EVERY
+    golden frame fitted side by side in ONE ``fit_batch`` call; the number of launches is bounded by the optimiser's
+    evaluation budget, not by the batch size."""
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    model, prior = assets
+    d = dict(np.load(H.GOLDEN / f"lbfgs_world_{case}.npz"))
+    it = int(d["max_iter"])
+    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=it, num_iters_followup=it, use_lbfgs=True,
+                              joints_category="AMASS", pose_prior=prior)
+    gen = torch.Generator().manual_seed(7)
+    n, trials = d["j3d"].shape[0], 5
+    rep = lambda k: torch.tensor(np.repeat(d[k], trials, axis=0))
+    noise = lambda x: x * (1 + 2e-6 * torch.randn(x.shape, generator=gen) * (torch.arange(x.shape[0]) % trials != 0).float()[:, None])
+    init = k2b.SMPLData(betas=rep("init_betas"), global_orient=noise(rep("init_global_orient")),
+                        body_pose=noise(rep("init_body_pose")), transl=noise(rep("init_transl")))
+    out, joints, _, loss = fitter.fit_batch(init, rep("j3d"), conf_3d=torch.tensor(d["conf"]), seq_ind=int(d["seq_ind"]),
+                                            freeze_betas=bool(int(d["freeze_betas"])))
+    assert fitter.last_lbfgs_rounds <= it * 5 // 4 + 2            # launches: the budget of ONE frame, whatever the batch
+    for i in range(n):
+        rows = slice(i * trials, (i + 1) * trials)
+        losses = loss[rows].cpu().numpy()
+        perr = [max(np.abs(out[key][r:r + 1].cpu().numpy() - d["out_" + key][i:i + 1]).max()
+                    for key in ("global_orient", "body_pose", "betas", "transl")) for r in range(rows.start, rows.stop)]
+        ref = (torch.tensor(d["out_joints"][i:i + 1, :22]) - torch.tensor(d["j3d"][i:i + 1])).norm(dim=-1).mean()
+        jerr = [abs(float((joints[r:r + 1, :22].cpu() - torch.tensor(d["j3d"][i:i + 1])).norm(dim=-1).mean()) - float(ref))
+                for r in range(rows.start, rows.stop)]
+        env = np.concatenate([d["out_loss_perturbed"][i], d["out_loss"][i:i + 1]])
+        med = float(np.median(losses))
+        assert 0.85 * env.min() <= med <= 1.15 * env.max(), (case, i, losses, env)
+        assert min(perr) < 5e-2, (case, i, perr)
+        assert max(jerr) < 1e-2, (case, i, jerr)
+    if int(d["freeze_betas"]):
+        assert torch.equal(out["betas"].cpu(), rep("init_betas"))
+
+
+def test_lbfgs_lockstep_frames_are_independent(assets):
+    """A frame's L-BFGS result does not depend on what else is in the batch (own history, own line search, own stop)."""
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    model, prior = assets
+    d = dict(np.load(H.GOLDEN / "lbfgs_world_first.npz"))
+    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=12, use_lbfgs=True, joints_category="AMASS", pose_prior=prior)
+    n = d["j3d"].shape[0]
+    t = lambda k, sl=slice(None): torch.tensor(d[k][sl])
+    mk = lambda sl: k2b.SMPLData(betas=t("init_betas", sl), global_orient=t("init_global_orient", sl), body_pose=t("init_body_pose", sl),
+                                 transl=t("init_transl", sl))
+    full, _, _, _ = fitter.fit_batch(mk(slice(None)), t("j3d"), conf_3d=t("conf"), seq_ind=0)
+    if n >= 3:
+        part, _, _, _ = fitter.fit_batch(mk(slice(1, 3)), t("j3d", slice(1, 3)), conf_3d=t("conf"), seq_ind=0)
+        for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+            assert torch.equal(full[k][1:3], part[k]), k
+
+
 def test_shape_pre_pass_and_default_config_sequence(assets):
     """optimize_shape_pass (shared betas, LBFGS) vs the reference's optimize_shape_multi_frame, then a
     whole optimize_params_sequence call with the reference's DEFAULT config (LBFGS + shape pre-pass)."""

@@ -130,3 +130,58 @@ def test_fitter_chain_through_the_sequence_api_runs_one_fit_launch():
         native.fit_sequence, native.fit_world = orig_s, orig_w
     assert len(res) == 4 and calls == {"seq": 1, "world": 0}
     assert all(tuple(r.vertices.shape) == (1, 6890, 3) for r in res)
+
+
+@pytest.mark.parametrize("name", H.CHAIN_CASES)
+def test_chain_launch_matches_reference_sequence_loop_on_real_motion(name):
+    """``k2b_fit_sequence`` against the REAL reference walked through its own frame loop (api/sequence.py:124-128, 214-281:
+    fix_foot confidences per frame, seq_ind = idx, prev = res.params) over the first frames of the reference's demo
+    motions (``tests/golden/chain_motion*.npz`` from oracle/gen_golden_chain.py): every frame's fitted parameters within
+    1e-4, its last-iteration loss within 1e-4 relative, and the final forward's joints / sampled vertices within 1e-4 m."""
+    from keypoints2body_amd import native
+    d = H.load_chain_case(name)
+    T = d["j3d"].shape[0]
+    cfg = native.default_fit_config()
+    cfg.num_iters = int(d["num_iters_first"])
+    cfg.pose_preserve_weight = 5.0
+    cfg.conf_per_frame = 1
+    out = native.fit_sequence(H.native_model(), H.native_prior(), cfg, int(d["num_iters_followup"]), list(range(22)),
+                              H.cuda(d["j3d"][None]), H.cuda(d["conf"][None]), H.cuda(d["init_global_orient"]),
+                              H.cuda(d["init_body_pose"]), H.cuda(d["init_betas"]), H.cuda(d["init_transl"]))
+    worst = 0.0
+    for k in ("global_orient", "body_pose", "betas", "transl"):
+        dev = (out[k][0].cpu() - torch.tensor(d["out_" + k])).abs().amax(dim=1)       # per frame
+        worst = max(worst, float(dev.max()))
+        assert float(dev.max()) < 1e-4, (k, dev.tolist())
+    rel = ((out["loss"][0].cpu() - torch.tensor(d["out_loss"])).abs() / torch.tensor(d["out_loss"]).abs()).max()
+    assert float(rel) < 1e-4, float(rel)
+    joints, verts = H.native_model().lbs(out["global_orient"][0], out["body_pose"][0], out["betas"][0], out["transl"][0])
+    assert float((joints.cpu() - torch.tensor(d["out_joints"])).abs().max()) < 1e-4
+    vid = torch.tensor(d["sampled_vertex_ids"])
+    assert float((verts.cpu()[:, vid] - torch.tensor(d["out_verts_sampled"])).abs().max()) < 1e-4
+    print(f"{name}: {T} frames, worst parameter deviation {worst:.2e}")
+
+
+def test_public_sequence_api_reproduces_reference_loop_on_real_motion():
+    """The same golden through ``optimize_params_sequence`` (fix_foot on, warm start, Adam, defaults 30 / 10): the public
+    function must apply the foot confidences itself and walk the chain as the reference's loop does."""
+    import keypoints2body_amd as k2b
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.models.smpl_data import SMPLData
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+    d = H.load_chain_case("chain_motion1_30_10")
+    g = H.gmm_fixture()
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    t = lambda k: torch.tensor(d[k])
+    init = SMPLData(betas=t("init_betas"), global_orient=t("init_global_orient"), body_pose=t("init_body_pose"),
+                    transl=t("init_transl"))
+    cfg = {"frame": {"use_lbfgs": False, "num_iters_first": 30, "num_iters_followup": 10}, "use_shape_optimization": False,
+           "use_previous_frame_init": True, "fix_foot": True}
+    res = k2b.optimize_params_sequence(d["j3d"], init_params=init, body_model="smpl", joint_layout="AMASS",
+                                       model=BodyModel.synthetic(0), config=cfg, pose_prior=prior,
+                                       mean_params=(torch.zeros(1, 72), torch.zeros(1, 10)))
+    assert len(res) == d["j3d"].shape[0]
+    for i, r in enumerate(res):
+        for k in ("global_orient", "body_pose", "betas", "transl"):
+            assert float((getattr(r.params, k).cpu() - t("out_" + k)[i:i + 1]).abs().max()) < 1e-4, (i, k)
+        assert float((r.joints.cpu() - t("out_joints")[i:i + 1]).abs().max()) < 1e-4, i

@@ -158,3 +158,27 @@ def test_oracle_reproduces_reference_smplh_fit(case):
     np.testing.assert_allclose(loss.numpy(), d["iter_losses"][:, -1], rtol=1e-5)
     if int(d["freeze_betas"]):
         assert np.array_equal(params["betas"].numpy(), d["init_betas"])
+
+
+@pytest.mark.parametrize("name", H.CHAIN_CASES)
+def test_oracle_chain_matches_reference_sequence_loop_on_real_motion(name):
+    """The oracle restatement walked through the reference's frame loop (api/sequence.py:214-281: per-frame fix_foot
+    confidences, ``seq_ind = idx``, every frame starting from - and preserving - its predecessor's RESULT) reproduces what
+    the real reference produced on the demo motions (fixtures of oracle/gen_golden_chain.py), frame by frame, at 1e-4."""
+    from oracle.fit_torch import fit_world_adam
+    torch.set_num_threads(8)
+    d = H.load_chain_case(name)
+    model, prior = H.oracle_model(), H.oracle_prior()
+    t = lambda k: torch.tensor(d[k])
+    cur = (t("init_global_orient"), t("init_body_pose"), t("init_betas"), t("init_transl"))
+    j3d, conf = t("j3d"), t("conf")
+    worst = 0.0
+    for i in range(j3d.shape[0]):
+        o = fit_world_adam(model, prior, *cur, j3d[i:i + 1], conf[i], seq_ind=i,
+                           num_iters=int(d["num_iters_first"] if i == 0 else d["num_iters_followup"]))
+        for k, v in (("global_orient", o.global_orient), ("body_pose", o.body_pose), ("betas", o.betas), ("transl", o.transl)):
+            worst = max(worst, float((v - t("out_" + k)[i:i + 1]).abs().max()))
+        assert abs(float(o.loss) - float(d["out_loss"][i])) <= 1e-4 * abs(float(d["out_loss"][i])), i
+        assert float((o.joints - t("out_joints")[i:i + 1]).abs().max()) < 1e-4, i
+        cur = (o.global_orient, o.body_pose, o.betas, o.transl)
+    assert worst < 1e-4, worst
