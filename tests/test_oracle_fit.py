@@ -163,22 +163,34 @@ def test_oracle_reproduces_reference_smplh_fit(case):
 @pytest.mark.parametrize("name", H.CHAIN_CASES)
 def test_oracle_chain_matches_reference_sequence_loop_on_real_motion(name):
     """The oracle restatement walked through the reference's frame loop (api/sequence.py:214-281: per-frame fix_foot
-    confidences, ``seq_ind = idx``, every frame starting from - and preserving - its predecessor's RESULT) reproduces what
-    the real reference produced on the demo motions (fixtures of oracle/gen_golden_chain.py), frame by frame, at 1e-4."""
+    confidences, ``seq_ind = idx``, every frame starting from - and preserving - its predecessor's RESULT) against what the
+    real reference produced on the demo motions (fixtures of oracle/gen_golden_chain.py).
+
+    Two gates.  TEACHER-FORCED, 1e-4 on every frame: frame t fitted from the REFERENCE's result of frame t-1 - pins the
+    per-frame semantics of the loop without error accumulation.  FREE-RUNNING: the chain amplifies rounding (the reference
+    walked again from a start perturbed by 2e-6 relative ends up to 2.6e-2 away from itself after 14 frames:
+    ``out_param_dev_perturbed`` in the fixture), so frame t may deviate by max(1e-4, 4 x the reference's own deviation)."""
     from oracle.fit_torch import fit_world_adam
     torch.set_num_threads(8)
     d = H.load_chain_case(name)
     model, prior = H.oracle_model(), H.oracle_prior()
     t = lambda k: torch.tensor(d[k])
-    cur = (t("init_global_orient"), t("init_body_pose"), t("init_betas"), t("init_transl"))
+    keys = ("global_orient", "body_pose", "betas", "transl")
     j3d, conf = t("j3d"), t("conf")
-    worst = 0.0
+    iters = lambda i: int(d["num_iters_first"] if i == 0 else d["num_iters_followup"])
+    cur = tuple(t("init_" + k) for k in keys)
     for i in range(j3d.shape[0]):
-        o = fit_world_adam(model, prior, *cur, j3d[i:i + 1], conf[i], seq_ind=i,
-                           num_iters=int(d["num_iters_first"] if i == 0 else d["num_iters_followup"]))
-        for k, v in (("global_orient", o.global_orient), ("body_pose", o.body_pose), ("betas", o.betas), ("transl", o.transl)):
-            worst = max(worst, float((v - t("out_" + k)[i:i + 1]).abs().max()))
+        # free-running
+        o = fit_world_adam(model, prior, *cur, j3d[i:i + 1], conf[i], seq_ind=i, num_iters=iters(i))
+        got = (o.global_orient, o.body_pose, o.betas, o.transl)
+        dev = max(float((v - t("out_" + k)[i:i + 1]).abs().max()) for k, v in zip(keys, got))
+        assert dev < max(1e-4, 4.0 * float(d["out_param_dev_perturbed"][i])), (i, dev)
+        cur = got
+        # teacher-forced
+        start = cur if i == 0 else tuple(t("out_" + k)[i - 1:i] for k in keys)
+        if i > 0:
+            o = fit_world_adam(model, prior, *start, j3d[i:i + 1], conf[i], seq_ind=i, num_iters=iters(i))
+        for k, v in zip(keys, (o.global_orient, o.body_pose, o.betas, o.transl)):
+            assert float((v - t("out_" + k)[i:i + 1]).abs().max()) < 1e-4, (i, k)
         assert abs(float(o.loss) - float(d["out_loss"][i])) <= 1e-4 * abs(float(d["out_loss"][i])), i
         assert float((o.joints - t("out_joints")[i:i + 1]).abs().max()) < 1e-4, i
-        cur = (o.global_orient, o.body_pose, o.betas, o.transl)
-    assert worst < 1e-4, worst
