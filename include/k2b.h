@@ -63,7 +63,7 @@ const char *k2b_last_error(void);
  *   j_regressor [J][V]        lbs_weights [V][J]        parents [J] (parents[0] = -1,
  *   extra_vertex_ids [E]      (output joints J..J+E-1 are these vertices)   parents[i] < i)
  * Limits: 2 <= J <= 64, 1 <= NB <= 32, E >= 0.  (24 joints with NB <= 16 run the 24-lane fused fit kernel,
- * everything else the tree kernel; the vertex kernels are built for 17-24 and 49-56 joints.)
+ * everything else the tree kernel; the vertex kernel is built for 17-24 and 49-56 joints.)
  * ------------------------------------------------------------------------------- */
 int k2b_model_create(k2b_model **out, int32_t num_vertices, int32_t num_joints, int32_t num_betas,
                      int32_t num_extra_joints, const float *v_template, const float *shapedirs,
@@ -207,9 +207,6 @@ int k2b_lbs(const k2b_model *model, int32_t num_frames, const float *global_orie
             const float *body_pose, const float *betas, const float *transl,
             float *joints_out, float *vertices_out, void *stream);
 
-/* Development knob (A/B timing only, not part of the product interface): 0 = the tile kernel (default),
- * 1 = the 128 x 64 kernel of round 1.  Process-wide. */
-void k2b_debug_lbs_kernel(int32_t which);
 /* Development: copies the first nbytes (<= 64 KiB) of the model's scratch row (where diagnostic builds leave their
  * in-kernel time stamps) to HOST memory; synchronises the device. */
 int k2b_debug_read_dump(const k2b_model *model, void *host, int64_t nbytes);

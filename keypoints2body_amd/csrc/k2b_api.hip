@@ -19,7 +19,6 @@
 namespace {
 
 thread_local std::string g_err;
-int g_lbs_kernel = 0;     // development knob (k2b_debug_lbs_kernel): 0 = tile kernel, 1 = the 128 x 64 kernel of round 1
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -74,10 +73,11 @@ struct k2b_model {
     std::vector<int> depth;                                  // depth of every joint (root 0)
     // LBS B operands (f16 hi/lo, MFMA fragment order) for the whole mesh and for the E extra-joint vertices
     struct VertexSet {
-        k2b::k2b_half *pdh = nullptr, *pdl = nullptr, *wth = nullptr, *wtl = nullptr;
+        k2b::k2b_half *pdh = nullptr, *pdl = nullptr;
         k2b::k2b_half* w2 = nullptr;                         // W in the tile kernel's group layout (k2b_internal.h, TileArgs)
         int v_tiles = 0, num = 0;
     } mesh, extra;
+    bool joints_in_mesh = false;                             // every extra joint's vertex is tagged in mesh.w2 (no gather launch)
     // tables of the tree fit kernel (any J <= 64), lane order = DFS pre-order
     float *tt_dt = nullptr, *tt_dd = nullptr;
     int *tt_tab = nullptr, *tt_anc = nullptr;
@@ -86,9 +86,9 @@ struct k2b_model {
     int groups_a = 0;                                        // GA = ceil(J / 8)
     k2b::k2b_half* wsA2 = nullptr;                           // per-frame A operand of the tile kernel
     float* dump = nullptr;                                   // 64 x 3 floats: store target of lanes outside the batch
-    int k_steps_x = 0, k_steps_a = 0;
+    int k_steps_x = 0;
     // LBS per-frame operand workspace (grow-only)
-    k2b::k2b_half *wsXh = nullptr, *wsXl = nullptr, *wsAh = nullptr, *wsAl = nullptr;
+    k2b::k2b_half *wsXh = nullptr, *wsXl = nullptr;
     int ws_bpad = 0;
     // Adam coefficient tables, one per (iters, lr, b1, b2); at most kMaxAdamTables, least recently used evicted
     struct AdamTable { float2* dev; uint64_t last_use; };
@@ -181,18 +181,17 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
     // LBS operands: B side of the two GEMMs, f16 hi/lo in fragment order (k2b_lbs.hip)
     {
         const int P = m->P;
-        const int KX = ((P + NB + 2 + 31) / 32) * 2, KA = (J + 15) / 16;   // even: the kernel stages 32-deep slices
+        const int KX = ((P + NB + 2 + 31) / 32) * 2;   // even: the kernel stages 32-deep slices
         m->k_steps_x = KX;
-        m->k_steps_a = KA;
         m->groups_a = k2b::tile_groups_a(J);
         HIP_TRY(hipMalloc((void**)&m->dump, 64 * 1024));     // 64 x 3 floats used; the rest is room for diagnostic builds
-        auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids) -> int {
+        // tag[i] = 1 + e when vertex i of the set is the vertex of output joint J + e (mesh set only), else 0
+        auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids, const std::vector<int>& tag) -> int {
             const int n = (int)ids.size();
             vs.num = n;
             vs.v_tiles = (n + 31) / 32;
             const int vp = vs.v_tiles * 32;
             std::vector<k2b::k2b_half> pdh((size_t)KX * 3 * vp * 16, (k2b::k2b_half)0.f), pdl(pdh.size(), (k2b::k2b_half)0.f);
-            std::vector<k2b::k2b_half> wth((size_t)KA * vp * 16, (k2b::k2b_half)0.f), wtl(wth.size(), (k2b::k2b_half)0.f);
             for (int i = 0; i < n; ++i) {
                 const int v = ids[i];
                 for (int c = 0; c < 3; ++c) {
@@ -215,13 +214,6 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                     const k2b::k2b_half rh = (k2b::k2b_half)rest;
                     put(P + NB + 1, rh, (k2b::k2b_half)(rest - (float)rh));
                 }
-                for (int j = 0; j < J; ++j) {
-                    const float w = lbs_weights[(size_t)v * J + j];
-                    const k2b::k2b_half hi = (k2b::k2b_half)w;
-                    const size_t o = k2b::frag_elem((size_t)(j >> 4) * vs.v_tiles + (i >> 5), j, i);
-                    wth[o] = hi;
-                    wtl[o] = (k2b::k2b_half)(w - (float)hi);
-                }
             }
             // tile-kernel layout of W: [16-vertex tile][hi groups | lo groups | ONES | ZERO][16 rows][8 joints]
             const int GA = k2b::tile_groups_a(J), NGP = k2b::tile_ngp(GA), v16 = vs.v_tiles * 2;
@@ -238,18 +230,25 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                             rowp[(size_t)(GA + (j >> 3)) * 128 + (j & 7)] = (k2b::k2b_half)(w - (float)hi);
                         }
                     for (int k = 0; k < 3; ++k) rowp[(size_t)(2 * GA) * 128 + k] = (k2b::k2b_half)1.f;   // ONES: picks up the PAD terms
+                    if (i < n && !tag.empty() && tag[i]) rowp[(size_t)(2 * GA + 1) * 128] = (k2b::k2b_half)(float)tag[i];   // ZERO group: joint tag
                 }
             hipError_t e;
             if ((e = upload(&vs.w2, w2.data(), w2.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdh, pdh.data(), pdh.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdl, pdl.data(), pdl.size())) != hipSuccess) return (int)e;
-            if ((e = upload(&vs.wth, wth.data(), wth.size())) != hipSuccess) return (int)e;
-            if ((e = upload(&vs.wtl, wtl.data(), wtl.size())) != hipSuccess) return (int)e;
             return 0;
         };
-        std::vector<int> all(V), ex(extra_vertex_ids, extra_vertex_ids + E);
+        std::vector<int> all(V), ex(extra_vertex_ids, extra_vertex_ids + E), tag(V, 0);
         for (int v = 0; v < V; ++v) all[v] = v;
-        if (build(m->mesh, all) != 0 || (E > 0 && build(m->extra, ex) != 0))
+        // an output joint rides in the W image of its vertex (k2b_lbs.hip) - unless two joints share a vertex or the index
+        // does not fit an f16 integer, in which case the gather launch stays
+        m->joints_in_mesh = E > 0 && E <= 1024;
+        for (int e = 0; e < E && m->joints_in_mesh; ++e) {
+            if (tag[extra_vertex_ids[e]]) m->joints_in_mesh = false;
+            tag[extra_vertex_ids[e]] = e + 1;
+        }
+        if (!m->joints_in_mesh) std::fill(tag.begin(), tag.end(), 0);
+        if (build(m->mesh, all, tag) != 0 || (E > 0 && build(m->extra, ex, std::vector<int>()) != 0))
             return fail(K2B_ERR_HIP, "k2b_model_create: uploading LBS operands failed");
     }
 
@@ -371,8 +370,7 @@ void k2b_model_destroy(k2b_model* m) {
     float* fl[] = {m->v_template, m->shapedirs, m->posedirs, m->j_regressor, m->lbs_weights, m->j_template,
                    m->j_dirs, m->dt, m->dd};
     for (float* p : fl) if (p) (void)hipFree(p);
-    k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->mesh.wth, m->mesh.wtl, m->extra.pdh, m->extra.pdl,
-                           m->extra.wth, m->extra.wtl, m->wsXh, m->wsXl, m->wsAh, m->wsAl, m->mesh.w2, m->extra.w2, m->wsA2};
+    k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->extra.pdh, m->extra.pdl, m->wsXh, m->wsXl, m->mesh.w2, m->extra.w2, m->wsA2};
     if (m->dump) (void)hipFree(m->dump);
     if (m->tt_dt) (void)hipFree(m->tt_dt);
     if (m->tt_dd) (void)hipFree(m->tt_dd);
@@ -386,7 +384,6 @@ void k2b_model_destroy(k2b_model* m) {
     delete m;
 }
 
-void k2b_debug_lbs_kernel(int32_t which) { g_lbs_kernel = which; }
 int k2b_debug_read_dump(const k2b_model* m, void* host, int64_t nbytes) {
     if (!m || !host || nbytes < 0 || nbytes > 64 * 1024) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_debug_read_dump: bad arguments");
     HIP_TRY(hipDeviceSynchronize());
@@ -929,22 +926,18 @@ namespace {
 int reserve_lbs_workspace(k2b_model* m, int bpad) {
     if (bpad <= m->ws_bpad) return K2B_OK;
     HIP_TRY(hipDeviceSynchronize());
-    k2b::k2b_half** ws[] = {&m->wsXh, &m->wsXl, &m->wsAh, &m->wsAl, &m->wsA2};
+    k2b::k2b_half** ws[] = {&m->wsXh, &m->wsXl, &m->wsA2};
     for (auto w : ws) { if (*w) HIP_TRY(hipFree(*w)); *w = nullptr; }
     m->ws_bpad = 0;
-    const size_t nx = (size_t)m->k_steps_x * bpad * 16, na = (size_t)12 * m->k_steps_a * bpad * 16;
+    const size_t nx = (size_t)m->k_steps_x * bpad * 16;
     const size_t na2 = (size_t)(bpad / 16) * 12 * k2b::tile_ngp(m->groups_a) * 128;
     HIP_TRY(hipMalloc((void**)&m->wsA2, na2 * sizeof(k2b::k2b_half)));
     HIP_TRY(hipMemset(m->wsA2, 0, na2 * sizeof(k2b::k2b_half)));    // PAD / ZERO groups and padding frames stay zero
     HIP_TRY(hipMalloc((void**)&m->wsXh, nx * sizeof(k2b::k2b_half)));
     HIP_TRY(hipMalloc((void**)&m->wsXl, nx * sizeof(k2b::k2b_half)));
-    HIP_TRY(hipMalloc((void**)&m->wsAh, na * sizeof(k2b::k2b_half)));
-    HIP_TRY(hipMalloc((void**)&m->wsAl, na * sizeof(k2b::k2b_half)));
     // rows of padding frames are never written by the set-up kernel: keep them finite
     HIP_TRY(hipMemset(m->wsXh, 0, nx * sizeof(k2b::k2b_half)));
     HIP_TRY(hipMemset(m->wsXl, 0, nx * sizeof(k2b::k2b_half)));
-    HIP_TRY(hipMemset(m->wsAh, 0, na * sizeof(k2b::k2b_half)));
-    HIP_TRY(hipMemset(m->wsAl, 0, na * sizeof(k2b::k2b_half)));
     m->ws_bpad = bpad;
     return K2B_OK;
 }
@@ -974,38 +967,29 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     k2b::PoseArgs pa{};
     pa.j_template = m->j_template; pa.j_dirs = m->j_dirs; pa.parents = m->parents;
     pa.num_joints = m->J; pa.num_betas = m->NB; pa.num_out_joints = m->J + m->E;
-    pa.num_frames = B; pa.frames_padded = bpad; pa.k_steps_x = m->k_steps_x; pa.k_steps_a = m->k_steps_a;
+    pa.num_frames = B; pa.frames_padded = bpad; pa.k_steps_x = m->k_steps_x;
     pa.go = go; pa.bp = bp; pa.be = be; pa.tr = tr;
-    const bool tiles = (m->groups_a == 3 || m->groups_a == 7) && g_lbs_kernel != 1;   // 17-24 or 49-56 joints
-    if (!tiles && (m->k_steps_a != 2))
-        return fail(K2B_ERR_UNSUPPORTED, "k2b_lbs: %d joints; the vertex kernels are built for 17-24 (SMPL) and 49-56 (SMPL-X) joints", m->J);
-    pa.xh = m->wsXh; pa.xl = m->wsXl; pa.joints_out = joints_out;
-    if (tiles) { pa.a2 = m->wsA2; } else { pa.ah = m->wsAh; pa.al = m->wsAl; }
+    if (m->groups_a != 3 && m->groups_a != 7)
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_lbs: %d joints; the vertex kernel is built for 17-24 (SMPL) and 49-56 (SMPL-H / SMPL-X) joints", m->J);
+    pa.xh = m->wsXh; pa.xl = m->wsXl; pa.a2 = m->wsA2; pa.joints_out = joints_out;
     HIP_TRY(k2b::launch_pose_setup(pa, stream));
-    auto skin = [&](const k2b_model::VertexSet& vs, float* out, int stride, int row0) -> hipError_t {
-        if (tiles) {
-            k2b::TileArgs ta{};
-            ta.xh = m->wsXh; ta.xl = m->wsXl; ta.a2 = m->wsA2; ta.pdh = vs.pdh; ta.pdl = vs.pdl; ta.w2 = vs.w2;
-            ta.groups_a = m->groups_a; ta.k_steps_x = m->k_steps_x; ta.f_tiles = bpad / 32; ta.v_tiles = vs.v_tiles;
-            ta.num_frames = B; ta.num_out = vs.num; ta.out = out; ta.out_stride = stride; ta.out_row0 = row0;
-            ta.dump = m->dump;
-            return k2b::launch_skin_tiles(ta, device_cus(), stream);
-        }
-        k2b::SkinArgs sa{};
-        sa.pdh = vs.pdh; sa.pdl = vs.pdl; sa.wth = vs.wth; sa.wtl = vs.wtl;
-        sa.v_tiles = vs.v_tiles; sa.num_out = vs.num;
-        sa.k_steps_x = m->k_steps_x; sa.k_steps_a = m->k_steps_a;
-        sa.num_frames = B; sa.frames_padded = bpad; sa.f_tiles = bpad / 32;
-        sa.xh = m->wsXh; sa.xl = m->wsXl; sa.ah = m->wsAh; sa.al = m->wsAl;
-        sa.tr = tr; sa.out = out; sa.out_stride = stride; sa.out_row0 = row0;
-        return k2b::launch_skin(sa, stream);
+    auto skin = [&](const k2b_model::VertexSet& vs, float* out, int stride, int row0, float* joint_copies) -> hipError_t {
+        k2b::TileArgs ta{};
+        ta.xh = m->wsXh; ta.xl = m->wsXl; ta.a2 = m->wsA2; ta.pdh = vs.pdh; ta.pdl = vs.pdl; ta.w2 = vs.w2;
+        ta.groups_a = m->groups_a; ta.k_steps_x = m->k_steps_x; ta.f_tiles = bpad / 32; ta.v_tiles = vs.v_tiles;
+        ta.num_frames = B; ta.num_out = vs.num; ta.out = out; ta.out_stride = stride; ta.out_row0 = row0;
+        ta.dump = m->dump;
+        ta.joints_out = joint_copies; ta.joints_stride = m->J + m->E; ta.joints_row0 = m->J;
+        return k2b::launch_skin_tiles(ta, device_cus(), stream);
     };
     if (vertices_out) {
-        HIP_TRY(skin(m->mesh, vertices_out, m->V, 0));
-        if (joints_out && m->E > 0)
+        // the mesh launch also writes the vertex-selected joints (their vertices are tagged in the W image)
+        const bool copies = joints_out && m->E > 0 && m->joints_in_mesh;
+        HIP_TRY(skin(m->mesh, vertices_out, m->V, 0, copies ? joints_out : nullptr));
+        if (joints_out && m->E > 0 && !copies)
             HIP_TRY(k2b::launch_gather_joints(vertices_out, m->extra_ids, joints_out, B, m->V, m->J, m->E, stream));
     } else if (joints_out && m->E > 0) {
-        HIP_TRY(skin(m->extra, joints_out, m->J + m->E, m->J));
+        HIP_TRY(skin(m->extra, joints_out, m->J + m->E, m->J, nullptr));
     }
     return K2B_OK;
 }

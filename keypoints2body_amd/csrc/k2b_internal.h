@@ -107,8 +107,8 @@ hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream);
 // LBS operands are f16 hi/lo pairs in MFMA fragment order: [k-step][row][16 halfs].
 constexpr float kPdScale = 256.0f;   // power-of-two scale of the vertex-GEMM B operand (keeps f16 lo terms normal)
 
-// Element (k, row) inside fragment number `frag` of a fragment-ordered operand: a fragment is the
-// 1 KiB a wave consumes for one 16-deep k-step of one 32-row tile, stored lane-linear:
+// Element (k, row) inside piece number `frag` of a piece-ordered operand: a piece is the
+// 1 KiB a wave moves for one 16-deep k-step of one 32-row tile, stored lane-linear:
 // [h = (k >> 3) & 1][row & 31][k & 7]  (lane 32 h + row owns 16 contiguous bytes).
 __host__ __device__ inline size_t frag_elem(size_t frag, int k, int row) {
     return ((frag * 2 + ((k >> 3) & 1)) * 32 + (row & 31)) * 8 + (k & 7);
@@ -123,34 +123,20 @@ struct PoseArgs {
     const int* parents;        // [J]
     int num_joints, num_betas, num_out_joints;
     int num_frames, frames_padded;
-    int k_steps_x, k_steps_a;  // 16-deep k-steps of the vertex GEMM (features) and of the transform GEMM (joints)
+    int k_steps_x;             // 16-deep k-steps of the vertex GEMM (features)
     const float *go, *bp, *be, *tr;  // tr may be null
-    k2b_half *xh, *xl;         // fragments [k_steps_x][frames_padded / 32]
-    k2b_half *ah, *al;         // fragments [12][k_steps_a][frames_padded / 32]   (null: not written)
-    k2b_half* a2;              // group layout of the tile kernel (see TileArgs), or null
+    k2b_half *xh, *xl;         // pieces [k_steps_x][frames_padded / 32]
+    k2b_half* a2;              // group layout of the tile kernel (see TileArgs)
     float* joints_out;         // [B][num_out_joints][3] (first J rows written) or null
 };
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream);
 int lbs_frames_padded(int num_frames);
 
-// One vertex set (the whole mesh, or the E vertex-selected joints) as B operands.
-struct SkinArgs {
-    const k2b_half *pdh, *pdl;   // fragments [k_steps_x][3][v_tiles]  (posedirs ; shapedirs ; template ; residual) * kPdScale
-    const k2b_half *wth, *wtl;   // fragments [k_steps_a][v_tiles]     skinning weights, k = joint
-    int v_tiles, num_out;        // 32-vertex tiles, real vertex count of the set
-    int k_steps_x, k_steps_a;
-    int num_frames, frames_padded, f_tiles;
-    const k2b_half *xh, *xl, *ah, *al;   // per-frame operands from the pose set-up
-    const float* tr;             // [B][3] or null
-    float* out;                  // [B][out_stride][3], rows out_row0 .. out_row0 + num_out - 1
-    int out_stride, out_row0;
-};
-hipError_t launch_skin(const SkinArgs& a, hipStream_t stream);
-
 // ---- tile kernel (k2b_lbs_tile_kernel): 128 frames x 128 vertices per workgroup, persistent ------------------
 // Operands of the transform GEMM T = A . W^T in k-GROUPS of 8 joints over 16-row tiles (256 B = [16 rows][8 halfs]):
 //   A  [16-frame tile][entry 12][NGP][16][8]   groups: hi_0..hi_{GA-1}, lo_0..lo_{GA-1}, PAD (translation terms), ZERO
 //   W  [16-vertex tile][NGP][16][8]            groups: hi_0..hi_{GA-1}, lo_0..lo_{GA-1}, ONES ([1,1,1,0,...] per row), ZERO
+//      (the ZERO group only ever meets zeros of A, so its first half per row is free to carry a tag: 1 + output joint of the vertex)
 // GA = ceil(J / 8), NGP = 2 GA + 2 (a multiple of 4: whole 1 KiB pieces).  The three f16-split products (hi.hi + hi.lo +
 // lo.hi) are ONE contraction over the concatenated group sequences  A: hi | hi | lo | PAD,  W: hi | lo | hi | ONES
 // (3 GA + 1 groups, padded to a multiple of four with ZERO): ceil((3 GA + 1) / 4) MFMAs of depth 32 per output tile, no
@@ -169,6 +155,10 @@ struct TileArgs {
     float* out;                  // [B][out_stride][3], rows out_row0 .. out_row0 + num_out - 1
     int out_stride, out_row0;
     float* dump;                 // >= 64 x 3 floats: where lanes without a valid (frame, vertex) put their store
+    // vertex-selected output joints (smplx's extra joints) written by the same launch: a vertex whose W row carries "1 + e" in
+    // its padding group is stored a second time, to joints_out[frame][joints_row0 + e]; null: no joint copies
+    float* joints_out;
+    int joints_stride, joints_row0;   // J + E, J
     int num_wgs;                 // grid size (a multiple of 8), set by the launcher
 };
 hipError_t launch_skin_tiles(const TileArgs& a, int num_cus, hipStream_t stream);

@@ -13,16 +13,17 @@
 //
 // Both run on the matrix cores.  fp32-input MFMA issues at the fp32 VALU rate, so operands are
 // split into two f16 terms (x = hi + lo, ~22 mantissa bits) and each product takes three
-// v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): 3/16 of the fp32 MFMA time
+// v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): 3/16 of the fp32 MFMA time
 // at fp32-level accuracy (|error| ~ 1e-6 m on metre-scale vertices; tests/test_gpu_parity.py).
+// (A single f16 term for the pose-corrective rows of Pd - two products instead of three - was priced in
+//  round 3: the dropped x_hi * Pd_lo product is 6.4e-6 m at the synthetic model's posedirs magnitude,
+//  over the 5e-6 gate)
 //
-// Tiling: a workgroup of 8 waves owns 128 frames x 64 vertices; each wave a 32 x 32 sub-tile.
-// MFMA orientation D[frame][vertex]: the accumulator of lane l holds 16 frames of ONE vertex
-// (column l & 31), so the skinning epilogue (T applied to v_posed) is a per-lane computation with
-// no cross-lane traffic.  Operands are stored as 1 KiB "fragments" in exactly the order the 64
-// lanes of a wave consume them ([k-step][32-row tile][k-half h][row][8 halfs]: lane 32 h + row
-// owns 16 contiguous bytes), so a fragment moves global -> LDS as one linear 1 KiB copy and is
-// read back with conflict-free ds_read_b128.
+// MFMA orientation D[frame][vertex]: a lane of the accumulator holds four frames of ONE vertex, so the
+// skinning epilogue (T applied to v_posed) is a per-lane computation with no cross-lane traffic and the
+// three coordinates of a (frame, vertex) pair leave as ONE 12-byte store.  Operands are stored in exactly
+// the order the 64 lanes of a wave consume them, in 1 KiB pieces, so a piece moves global -> LDS as one
+// linear copy (global_load_lds_dwordx4) and is read back with conflict-free ds_read_b128.
 #include <hip/hip_fp16.h>
 
 #include "k2b_internal.h"
@@ -30,15 +31,7 @@
 namespace k2b {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 struct __attribute__((packed, aligned(4))) float3v { float x, y, z; };
-
-// Fragment number of transform entry `entry` (0..11 = 4 r + e), k-step ks, frame tile `tile`:
-// [entry >> 1][ks][entry & 1][tile]: the six entry pairs are consecutive slices a constant stride
-// apart, each holding both entries of the pair for every joint k-step.
-__device__ __forceinline__ size_t a_frag(int entry, int ks, int k_steps, int tiles, int tile) {
-    return ((size_t)((entry >> 1) * k_steps + ks) * 2 + (entry & 1)) * tiles + tile;
-}
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -50,6 +43,9 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxXSteps = 32;       // 16-deep k-steps of the feature vector this kernel can stage (SMPL: 14, SMPL-X: 32)
 
+// NBC = capacity of the shape loop (10 / 16 / 20 / 32: the unrolled J(beta) loads and products are a third of this
+// kernel's instructions at 32), GA = ceil(J / 8) (compile-time divisors in the A2 store loop)
+template <int NBC, int GA>
 __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     __shared__ float sR[kMaxJoints][9];
     __shared__ float sd[kMaxJoints][3];
@@ -70,18 +66,18 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         const float* src = j == 0 ? a.go + (size_t)f * 3 : a.bp + (size_t)f * 3 * (J - 1) + 3 * (j - 1);
         th = {src[0], src[1], src[2]};
         par = a.parents[j];
-        float beta[kMaxShape];
+        float beta[NBC];
 #pragma unroll
-        for (int k = 0; k < kMaxShape; ++k) beta[k] = k < NB ? a.be[(size_t)f * NB + k] : 0.f;
+        for (int k = 0; k < NBC; ++k) beta[k] = k < NB ? a.be[(size_t)f * NB + k] : 0.f;
         float e[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float dir[kMaxShape];
+            float dir[NBC];
 #pragma unroll
-            for (int k = 0; k < kMaxShape; ++k) dir[k] = k < NB ? a.j_dirs[(j * 3 + c) * NB + k] : 0.f;
+            for (int k = 0; k < NBC; ++k) dir[k] = k < NB ? a.j_dirs[(j * 3 + c) * NB + k] : 0.f;
             float s = a.j_template[j * 3 + c];
 #pragma unroll
-            for (int k = 0; k < kMaxShape; ++k) s += dir[k] * beta[k];      // same order of additions as before
+            for (int k = 0; k < NBC; ++k) s += dir[k] * beta[k];      // (k >= NB adds exact zeros: same sum for every capacity)
             e[c] = s;
         }
         Jj = {e[0], e[1], e[2]};
@@ -156,12 +152,6 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
             const uint4 v = *reinterpret_cast<const uint4*>((lo ? sXl : sXh) + ks * 16 + 8 * h);
             *reinterpret_cast<uint4*>((lo ? a.xl : a.xh) + frag_elem((size_t)ks * tiles + tile, 8 * h, f)) = v;
         }
-        const int na = a.ah ? 12 * a.k_steps_a * 2 : 0;    // chunks per A array (fragment layout of the 128 x 64 kernel)
-        for (int c = j; c < 2 * na; c += 64) {
-            const int lo = c >= na, cc = lo ? c - na : c, e = cc / (a.k_steps_a * 2), r = cc % (a.k_steps_a * 2), ks = r >> 1, h = r & 1;
-            const uint4 v = *reinterpret_cast<const uint4*>((lo ? &sAl[e][0] : &sAh[e][0]) + ks * 16 + 8 * h);
-            *reinterpret_cast<uint4*>((lo ? a.al : a.ah) + frag_elem(a_frag(e, ks, a.k_steps_a, tiles, tile), 8 * h, f)) = v;
-        }
     }
     if (a.a2) {
         // group layout of the tile kernel: [16-frame tile][entry][hi groups | lo groups | PAD | ZERO][row 16][8]; the PAD group of
@@ -173,7 +163,8 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
             for (int i = 3; i < 8; ++i) sTp[j][i] = (_Float16)0.f;
         }
         __syncthreads();
-        const int GA = (J + 7) >> 3, NGP = 2 * GA + 2, tile = f >> 4, row = f & 15;
+        constexpr int NGP = 2 * GA + 2;
+        const int tile = f >> 4, row = f & 15;
         k2b_half* base = a.a2 + ((size_t)tile * 12 * NGP * 16 + row) * 8;
         for (int c = j; c < 12 * 2 * GA + 3; c += 64) {
             uint4 v;
@@ -199,217 +190,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Vertex kernel: workgroup = 8 waves = 4 frame tiles x 2 vertex tiles (128 frames x 64 vertices).
-//
-// Slices staged through LDS (double-buffered), one barrier per slice, exactly 5 (pose) or 4
-// (transform) fragments loaded per wave and slice from precomputed pointers that advance by a
-// constant stride - the per-slice bookkeeping is a handful of scalar adds:
-//   pose slice  s (32-deep: k-steps 2s, 2s+1): 16 X + 24 Pd fragments, 18 MFMAs per wave
-//   transform slice t = entry pair (6)       : 32 A fragments (2 entries x 2 joint k-steps), 12 MFMAs per wave
-// The skinning-weight fragments (KA x 2 tiles x hi/lo) are loaded once and stay resident.
-// ---------------------------------------------------------------------------------------------
-constexpr int kChunkGroups = 4;      // frame groups (128 frames each) per L2-resident chunk
-constexpr int kFragHalfs = 512;      // one fragment = 64 lanes x 8 halfs = 1 KiB
-constexpr int kSlotFrags = 40;       // fragments per ring slot
-
-__global__ __launch_bounds__(512, 1) void k2b_lbs_mfma_kernel(const SkinArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 ring[2][kSlotFrags][kFragHalfs];   // 80 KiB
-    __shared__ __attribute__((aligned(16))) _Float16 wres[8][kFragHalfs];               // 8 KiB (KA == 2)
-    __shared__ __attribute__((aligned(16))) float parked[8][2][4][64][4];               // 64 KiB: x, y of each lane's 16 results
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar addressing
-    const int ftl = wave >> 1, vtl = wave & 1;      // this wave's sub-tile inside the workgroup tile
-    const int h = lane >> 5, col = lane & 31;
-
-    // Rasterisation for the 8 per-XCD L2s (blocks are dealt round-robin over the XCDs, so b % 8
-    // labels blocks that share an L2): each label owns every 8th vertex group, and inside a chunk
-    // of kChunkGroups frame groups the frame index runs fastest - the vertex operands of one group
-    // (172 KB) stay L2-resident while the chunk's frames sweep over them, and the chunk's per-frame
-    // operands (1.2 MB) stay resident while the vertex groups advance.  Placement affects speed only.
-    const int vgroups = (a.v_tiles + 1) / 2, fgroups = (a.f_tiles + 3) / 4;
-    const int vl = (vgroups + 7) / 8;
-    const int label = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    const int chunk = bi / (vl * kChunkGroups), rem = bi % (vl * kChunkGroups);
-    const int vg = (rem / kChunkGroups) * 8 + label, fg = chunk * kChunkGroups + rem % kChunkGroups;
-    if (vg >= vgroups || fg >= fgroups) return;     // whole workgroup leaves together
-    const int ftiles = a.f_tiles, vtiles = a.v_tiles;
-    const int KS2 = a.k_steps_x / 2, KA = a.k_steps_a;   // k_steps_x is even (k2b_model_create)
-    // tiles past the end are clamped for loading (their results are never stored)
-    auto ftile = [&](int t) { const int x = fg * 4 + t; return x < ftiles ? x : ftiles - 1; };
-    auto vtile = [&](int t) { const int x = vg * 2 + t; return x < vtiles ? x : vtiles - 1; };
-
-    // ---- source pointers of this wave's fragment slots (q = wave + 8 i), computed once -------------
-    const _Float16* psrc[5];     // pose slices
-    size_t pstride[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int q = wave + 8 * i;
-        if (q < 16) {            // X: [ksl][ft][hl]
-            const int ksl = q >> 3, ft = (q >> 1) & 3;
-            psrc[i] = ((q & 1) ? a.xl : a.xh) + ((size_t)ksl * ftiles + ftile(ft)) * kFragHalfs + lane * 8;
-            pstride[i] = (size_t)2 * ftiles * kFragHalfs;
-        } else {                 // Pd: [ksl][vt][c][hl]
-            const int i2 = q - 16, ksl = i2 / 12, r12 = i2 % 12, vt = r12 / 6, c = (r12 % 6) >> 1;
-            psrc[i] = ((i2 & 1) ? a.pdl : a.pdh) + (((size_t)ksl * 3 + c) * vtiles + vtile(vt)) * kFragHalfs + lane * 8;
-            pstride[i] = (size_t)2 * 3 * vtiles * kFragHalfs;
-        }
-    }
-    const _Float16* asrc[4];     // transform slices: A [ft][ks][e2][hl]   (KA == 2: checked by the launcher)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave + 8 * i, ft = q >> 3, kse = (q >> 1) & 3;
-        asrc[i] = ((q & 1) ? a.al : a.ah) + ((size_t)kse * ftiles + ftile(ft)) * kFragHalfs + lane * 8;
-    }
-    const size_t astride = (size_t)4 * ftiles * kFragHalfs;
-
-
-    // Operand slices travel global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane x 16 B,
-    // which is exactly the lane-linear 1 KiB fragment): no staging registers and no LDS writes in the waves'
-    // instruction streams.  The loads of slice s + 1 are issued at the top of slice s into the other ring slot;
-    // the barrier at the end of the slice drains them (hipcc waits vmcnt(0) in front of __syncthreads).
-    auto load_pose = [&](int slot) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            __builtin_amdgcn_global_load_lds(psrc[i], &ring[slot][wave + 8 * i][0], 16, 0, 0);
-            psrc[i] += pstride[i];
-        }
-    };
-    auto load_a = [&](int slot) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(asrc[i], &ring[slot][wave + 8 * i][0], 16, 0, 0);
-            asrc[i] += astride;
-        }
-    };
-    auto frag = [&](int slot, int q) -> half8 { return *reinterpret_cast<const half8*>(&ring[slot][q][lane * 8]); };
-
-    floatx16 acc[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
-
-    const int nslices = KS2 + 6;
-    load_pose(0);
-    // ---- resident skinning weights: fragment (ks, vt, hl) -> wres[(ks * 2 + vt) * 2 + hl], requested together with the
-    // first slice (one round trip to L2 in front of the first barrier instead of two) ------------
-    for (int q = wave; q < KA * 4; q += 8) {
-        const int ks = q >> 2, vt = (q >> 1) & 1;
-        const _Float16* src = ((q & 1) ? a.wtl : a.wth) + ((size_t)ks * vtiles + vtile(vt)) * kFragHalfs + lane * 8;
-        __builtin_amdgcn_global_load_lds(src, &wres[q][0], 16, 0, 0);
-    }
-    __syncthreads();
-
-    // ---- phase 1: v_posed * kPdScale = X . Pd for the three coordinates -----------------------------
-    for (int s = 0; s < KS2; ++s) {
-        const int slot = s & 1, nslot = slot ^ 1;
-        const bool next_pose = s + 1 < KS2;
-        if (next_pose) load_pose(nslot); else load_a(nslot);
-        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the slice: its latency hides under the MFMAs
-#pragma unroll
-        for (int ksl = 0; ksl < 2; ++ksl) {
-            const half8 xh = frag(slot, ksl * 8 + ftl * 2), xl = frag(slot, ksl * 8 + ftl * 2 + 1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int q = 16 + ksl * 12 + vtl * 6 + c * 2;
-                const half8 ph = frag(slot, q), pl = frag(slot, q + 1);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, ph, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, pl, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, ph, acc[c], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-    const float inv_scale = 1.0f / kPdScale;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[c][i] *= inv_scale;
-
-    // ---- phase 2: out_r = T[4r..4r+3] . [v_posed; 1] + transl, T = A . W^T ----------------------------
-    // One slice per entry pair (T[4r], T[4r+1]) / (T[4r+2], T[4r+3]): two 32x32 accumulators live.
-    const int ft = fg * 4 + ftl, vt = vg * 2 + vtl;
-    const int v = vt * 32 + col;
-    const bool store_ok = ft < ftiles && vt < vtiles && v < a.num_out;
-    // frame of accumulator register i (C/D map of 32x32 MFMA: column = lane & 31,
-    // row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)), clamped for the translation prefetch
-    const int frow0 = ft * 32 + 4 * h;
-    const int flast = a.num_frames - 1;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        float outp[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {      // start from the translation of the frame this register holds
-            const int f = frow0 + (i & 3) + 8 * (i >> 2);
-            outp[i] = a.tr ? a.tr[(size_t)(f < flast ? f : flast) * 3 + r] : 0.f;
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int s = KS2 + 2 * r + half, slot = s & 1, nslot = slot ^ 1;
-            const bool more = s + 1 < nslices;
-            if (more) load_a(nslot);
-            __builtin_amdgcn_sched_barrier(0);
-            floatx16 t2[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) t2[e][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const half8 wh = *reinterpret_cast<const half8*>(&wres[(ks * 2 + vtl) * 2][lane * 8]);
-                const half8 wl = *reinterpret_cast<const half8*>(&wres[(ks * 2 + vtl) * 2 + 1][lane * 8]);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const half8 ah = frag(slot, ftl * 8 + ks * 4 + e * 2), al = frag(slot, ftl * 8 + ks * 4 + e * 2 + 1);
-                    t2[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, t2[e], 0, 0, 0);
-                    t2[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, t2[e], 0, 0, 0);
-                    t2[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, t2[e], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                outp[i] += half == 0 ? t2[0][i] * acc[0][i] + t2[1][i] * acc[1][i] : t2[0][i] * acc[2][i] + t2[1][i];
-        }
-        // Coordinates 0 and 1 are parked in a lane-private LDS area (4 x 16 B per lane and coordinate);
-        // with the third, every vertex leaves as ONE 12-byte store (a wave instruction covers
-        // 32 vertices x 12 B = 384 contiguous bytes per frame row).  Per-coordinate 4-byte stores
-        // reached HBM as partial lines three times over (WRITE_SIZE 2.8x the algorithmic bytes).
-        if (r < 2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(&parked[wave][r][g][lane][0]) =
-                    make_float4(outp[4 * g], outp[4 * g + 1], outp[4 * g + 2], outp[4 * g + 3]);
-        } else if (store_ok) {
-            float* orow = a.out + ((size_t)a.out_row0 + v) * 3;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 px = *reinterpret_cast<const float4*>(&parked[wave][0][g][lane][0]);
-                const float4 py = *reinterpret_cast<const float4*>(&parked[wave][1][g][lane][0]);
-                const float xs4[4] = {px.x, px.y, px.z, px.w}, ys4[4] = {py.x, py.y, py.z, py.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = 4 * g + k;
-                    const int f = frow0 + (i & 3) + 8 * (i >> 2);
-                    float3v o;
-                    o.x = xs4[k];
-                    o.y = ys4[k];
-                    o.z = outp[i];
-#ifdef K2B_LBS_NOSTORE   // timing-only diagnostic build: keep the value live, drop the store
-                    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z));
-                    (void)orow;
-#else
-                    if (f <= flast) *reinterpret_cast<float3v*>(orow + (size_t)f * a.out_stride * 3) = o;
-#endif
-                }
-            }
-        }
-    }
-}
+constexpr int kFragHalfs = 512;      // one piece = 64 lanes x 8 halfs = 1 KiB
 
 // ---------------------------------------------------------------------------------------------
 // Tile kernel: workgroup = 8 waves = 128 frames x 128 vertices, persistent; v_mfma_f32_16x16x32_f16 throughout.
@@ -432,16 +213,21 @@ __global__ __launch_bounds__(512, 1) void k2b_lbs_mfma_kernel(const SkinArgs a) 
 // ---------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int kTileSlotBytes = 64 * 1024;
-// Timing-only diagnostic builds (tools/build_lbs_variants.sh; never the shipped library):
-//   K2B_TILE_DIAG 1: every store goes to the dump row     2: only the first slice is ever filled (stale LDS afterwards)
-//   3: no MFMAs (fills, LDS reads, barriers, stores only)  5: stores land in the rows of the first 32 frames only (an
-//   L2-resident footprint: no HBM write stream)            6: s_memtime stamps of every slice of one tile (tools/dev_lbs_stamps.py)
-//   K2B_TILE_CHUNK: frame groups per L2 chunk (default 8)
-#ifndef K2B_TILE_DIAG
-#define K2B_TILE_DIAG 0
+// Timing-only diagnostic builds (no stores / no fills / no MFMAs / L2-resident stores / s_memtime stamps) live outside this file:
+// tools/build_lbs_variants.sh compiles it with -DK2B_LBS_DIAG_HEADER=<tools/lbs_diag.h>, which redefines the hooks below.
+#ifdef K2B_LBS_DIAG_HEADER
+#include K2B_LBS_DIAG_HEADER
+#else
+#define K2B_DIAG_SKIP_FILL(lq) false              // true: this slice's fills are not issued
+#define K2B_DIAG_STORE(f, ok) ((void)0)           // may redirect the frame row / validity of a store
+#define K2B_DIAG_MFMA(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0)
+#define K2B_DIAG_STAMP_DECL ((void)0)
+#define K2B_DIAG_STAMP(slice, k) ((void)0)
+#define K2B_DIAG_TILE_DONE ((void)0)
+#define K2B_DIAG_KERNEL_END ((void)0)
 #endif
 #ifndef K2B_TILE_CHUNK
-#define K2B_TILE_CHUNK 8
+#define K2B_TILE_CHUNK 8      // frame groups per L2 chunk of the tile walk
 #endif
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -475,14 +261,7 @@ struct TileWalk {
     }
 };
 
-__device__ __forceinline__ floatx4 tile_mfma(half8 x, half8 y, floatx4 c) {
-#if K2B_TILE_DIAG == 3
-    asm volatile("" ::"v"(x), "v"(y));      // operands stay live (their LDS reads are kept), no matrix instruction
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0);
-#endif
-}
+__device__ __forceinline__ floatx4 tile_mfma(half8 x, half8 y, floatx4 c) { return K2B_DIAG_MFMA(x, y, c); }
 
 template <int GA, int EPS>
 __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
@@ -539,9 +318,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     const unsigned vstride = lane < 4 ? 2u * ftiles * kFragHalfs : 2u * 3u * vtiles * kFragHalfs;   // per 32-deep k-step
     auto issue = [&]() {
         if (!lw.valid) return;
-#if K2B_TILE_DIAG == 2
-        if (lq > 0) { ++lq; if (++ls == spt) { ls = 0; lw.next(); } return; }
-#endif
+        if (K2B_DIAG_SKIP_FILL(lq)) { ++lq; if (++ls == spt) { ls = 0; lw.next(); } return; }
         unsigned char* slot = lds + (lq & 1) * kTileSlotBytes;
         if (ls < KX) {
             if (ls == 0) {        // new tile: offsets of the pieces at k-step 0 (lane i: piece p = lwv + 4 i)
@@ -594,17 +371,8 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
     auto rd = [&](const unsigned char* base, int off) -> half8 { return *reinterpret_cast<const half8*>(base + off); };
     const float inv_scale = 1.0f / kPdScale;
     float* const dump = a.dump + lane * 3;
-#if K2B_TILE_DIAG == 6
-    // stamps of the workgroup's THIRD tile, all 8 waves, 8 per slice, kept in the unused 16 KiB of LDS (no vector-memory
-    // traffic, so the counted waits are undisturbed) and copied out at the end by the blocks 0 and 77
-    unsigned* const stamps = reinterpret_cast<unsigned*>(wimg + 8 * NGP * 256);
-    int tile_no = 0;
-    auto stamp = [&](int slice, int k) {
-        if (tile_no == 2 && lane == 0) stamps[(wave * 32 + slice) * 8 + k] = (unsigned)__builtin_amdgcn_s_memtime();
-    };
-#else
-    auto stamp = [&](int, int) {};
-#endif
+    K2B_DIAG_STAMP_DECL;
+    auto stamp = [&](int slice, int k) { K2B_DIAG_STAMP(slice, k); };
 
     // one 12-byte store per (frame, vertex) of a 16-frame unit: frame fbase0 + 4 g + i, 16-vertex tile v
     auto emit_stores = [&](const floatx4 (&o)[2][3], int fbase0, int vg) {
@@ -614,16 +382,9 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-#if K2B_TILE_DIAG == 5
-                const int f = (fbase0 + 4 * g + i) & 31;
-                const bool ok = true;
-#elif K2B_TILE_DIAG == 1
-                const int f = 0;
-                const bool ok = false;
-#else
-                const int f = fbase0 + 4 * g + i;
-                const bool ok = f < a.num_frames && v0 + 16 * v < a.num_out;
-#endif
+                int f = fbase0 + 4 * g + i;
+                bool ok = f < a.num_frames && v0 + 16 * v < a.num_out;
+                K2B_DIAG_STORE(f, ok);
                 float3v x;
                 x.x = o[v][0][i]; x.y = o[v][1][i]; x.z = o[v][2][i];
                 float* dst = ok ? orow + ((size_t)f * a.out_stride + 16 * v) * 3 : dump;
@@ -640,7 +401,8 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
         stored = pend_valid;
         if (pend_valid) { emit_stores(pend, pend_f, pend_vg); pend_valid = false; }
     };
-    auto loader_wait = [&]() {    // the fills have landed; the eight stores behind them may fly on
+    auto loader_wait = [&]() {    // the fills have landed; the eight stores behind them may fly on (joint copies stored later in the
+                                  // slice are younger still: "at most 8 outstanding" keeps meaning "every fill has landed")
         if (stored) wait_vmcnt<8>(); else wait_vmcnt<0>();
     };
 
@@ -736,6 +498,19 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int k = 0; k < NKT; ++k) wf[v][k] = rd(wb, v * NGP * 256 + offW[k]);
+        // vertex-selected extra joints ride in the W image: first half of the (otherwise all-zero) padding group of a vertex's row =
+        // 1 + index of the output joint that IS this vertex (0: none).  It multiplies zeros of A in the GEMM.  A wave whose 32
+        // vertices hold such a vertex stores that vertex a second time, into the joints array (rare: 21 of 6890 for SMPL) -
+        // which replaces the gather launch that used to follow this kernel.
+        int jrow[2];
+        bool has_joint = false;
+        if (a.joints_out) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                jrow[v] = (int)(float)*reinterpret_cast<const _Float16*>(wb + v * NGP * 256 + (2 * GA + 1) * 256 + (opaque_lane() & 15) * 16);
+            }
+            has_joint = __builtin_amdgcn_ballot_w64(jrow[0] != 0 || jrow[1] != 0) != 0;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             floatx4 out[2][3];
@@ -794,6 +569,19 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 stamp(KX + u * NTS + ts, 2);
                 if (ts == NTS - 1) {
                     const int fbase0 = (cw.fg * 4 + 2 * fpair) * 32 + u * 16;
+                    if (has_joint) {
+#pragma unroll
+                        for (int v = 0; v < 2; ++v)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int f = fbase0 + 4 * g + i;
+                                if (jrow[v] != 0 && f < a.num_frames) {
+                                    float3v x;
+                                    x.x = out[v][0][i]; x.y = out[v][1][i]; x.z = out[v][2][i];
+                                    *reinterpret_cast<float3v*>(a.joints_out + ((size_t)f * a.joints_stride + a.joints_row0 + jrow[v] - 1) * 3) = x;
+                                }
+                            }
+                    }
                     if (loader) {
 #pragma unroll
                         for (int v = 0; v < 2; ++v)
@@ -813,22 +601,14 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
             }
         }
         cw.next();
-#if K2B_TILE_DIAG == 6
-        ++tile_no;
-#endif
+        K2B_DIAG_TILE_DONE;
     }
     if (loader && pend_valid) emit_stores(pend, pend_f, pend_vg);
     wait_vmcnt<0>();
-#if K2B_TILE_DIAG == 6
-    if (blockIdx.x == 0 || blockIdx.x == 77) {
-        wg_barrier();
-        unsigned* dst = reinterpret_cast<unsigned*>(a.dump) + 1024 + (blockIdx.x ? 2048 : 0);
-        for (int i = threadIdx.x; i < 8 * 32 * 8; i += 512) dst[i] = stamps[i];
-    }
-#endif
+    K2B_DIAG_KERNEL_END;
 }
 
-// joints J..J+E-1 := vertices[extra ids] (when the full mesh has just been produced)
+// joints J..J+E-1 := vertices[extra ids]: only when an output joint's vertex cannot ride in the W image (two joints on one vertex)
 __global__ void k2b_gather_joints_kernel(const float* __restrict__ verts, const int* __restrict__ ids, float* joints,
                                          int num_frames, int V, int J, int E) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -843,18 +623,14 @@ int lbs_frames_padded(int num_frames) { return (num_frames + 31) / 32 * 32; }
 
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream) {
     if (a.num_frames <= 0) return hipSuccess;
-    if (a.k_steps_x > kMaxXSteps || a.num_joints > kMaxJoints || (a.ah && (a.k_steps_a * 16 > 32 || a.num_joints > 32)))
-        return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k2b_pose_setup_kernel, dim3(a.num_frames), dim3(64), 0, stream, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_skin(const SkinArgs& a, hipStream_t stream) {
-    if (a.num_frames <= 0 || a.num_out <= 0) return hipSuccess;
-    if (a.k_steps_a != 2 || (a.k_steps_x & 1)) return hipErrorInvalidValue;   // 17..32 joints (SMPL: 24)
-    const int vgroups = (a.v_tiles + 1) / 2, fgroups = (a.f_tiles + 3) / 4;
-    const int vl = (vgroups + 7) / 8, chunks = (fgroups + kChunkGroups - 1) / kChunkGroups;
-    hipLaunchKernelGGL(k2b_lbs_mfma_kernel, dim3(8 * vl * kChunkGroups * chunks), dim3(512), 0, stream, a);
+    if (a.k_steps_x > kMaxXSteps || a.num_joints > kMaxJoints || a.num_betas > kMaxShape) return hipErrorInvalidValue;
+    const int GA = tile_groups_a(a.num_joints);
+    const dim3 grid(a.num_frames), block(64);
+#define K2B_POSE(NBC_, GA_) hipLaunchKernelGGL((k2b_pose_setup_kernel<NBC_, GA_>), grid, block, 0, stream, a)
+    if (GA == 3) { if (a.num_betas <= 10) K2B_POSE(10, 3); else if (a.num_betas <= 16) K2B_POSE(16, 3); else K2B_POSE(32, 3); }
+    else if (GA == 7) { if (a.num_betas <= 10) K2B_POSE(10, 7); else if (a.num_betas <= 20) K2B_POSE(20, 7); else K2B_POSE(32, 7); }
+    else return hipErrorInvalidValue;                      // 17..24 joints (SMPL) or 49..56 (SMPL-H / SMPL-X)
+#undef K2B_POSE
     return hipGetLastError();
 }
 
@@ -872,9 +648,9 @@ hipError_t launch_skin_tiles(const TileArgs& a_in, int num_cus, hipStream_t stre
     hipError_t e = hipSuccess;
 #define K2B_TILE(GA_, EPS_)                                                                                          \
     do {                                                                                                             \
-        static std::atomic<unsigned long long> lds_set{0};                                                             \
-        e = ensure_dynamic_lds(k2b_lbs_tile_kernel<GA_, EPS_>, lds_set, lds);                                    \
-        if (e != hipSuccess) return e;                                                                                 \
+        static std::atomic<unsigned long long> lds_set{0};                                                           \
+        e = ensure_dynamic_lds(k2b_lbs_tile_kernel<GA_, EPS_>, lds_set, lds);                                        \
+        if (e != hipSuccess) return e;                                                                               \
         hipLaunchKernelGGL((k2b_lbs_tile_kernel<GA_, EPS_>), dim3(wgs), dim3(512), lds, stream, a);                  \
     } while (0)
     if (GA == 3) K2B_TILE(3, 12);

@@ -25,7 +25,7 @@ K2B_ERR_NO_DEVICE = -4
 
 EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
-    "k2b_model_joint_basis", "k2b_model_reserve", "k2b_debug_lbs_kernel", "k2b_debug_read_dump", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
+    "k2b_model_joint_basis", "k2b_model_reserve", "k2b_debug_read_dump", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
     "k2b_fit_world", "k2b_fit_sequence", "k2b_lbs", "k2b_vertex_term", "k2b_adam_step", "k2b_angular_error_deg",
 )
 
@@ -85,8 +85,6 @@ def load_library():
     lib.k2b_model_dims.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
     lib.k2b_debug_read_dump.restype = C.c_int
     lib.k2b_debug_read_dump.argtypes = [vp, vp, C.c_int64]
-    lib.k2b_debug_lbs_kernel.restype = None
-    lib.k2b_debug_lbs_kernel.argtypes = [C.c_int32]
     lib.k2b_model_reserve.restype = C.c_int
     lib.k2b_model_reserve.argtypes = [vp, C.c_int32]
     lib.k2b_model_joint_basis.restype = C.c_int

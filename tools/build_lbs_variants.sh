@@ -1,10 +1,12 @@
 #!/bin/bash
 # Timing-only variants of the LBS tile kernel: tools/libk2b_<name>.so (git-ignored; they travel to the GPU box).
+# The diagnostics themselves live in tools/lbs_diag.h (hooks the shipped kernel leaves empty).
 # usage: tools/build_lbs_variants.sh name:"-DFLAGS" ...     e.g.  nostore:"-DK2B_TILE_DIAG=1" chunk4:"-DK2B_TILE_CHUNK=4"
 set -e
 cd "$(dirname "$0")/../keypoints2body_amd/csrc"
 make -s -j8
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast -fno-slp-vectorize"
+DIAG="$(cd ../../tools && pwd)/lbs_diag.h"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast -fno-slp-vectorize -DK2B_LBS_DIAG_HEADER=\"$DIAG\""
 for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_lbs.hip -o /tmp/k2b_lbs_$name.o

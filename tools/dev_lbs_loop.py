@@ -24,3 +24,11 @@ for _ in range(9):
     ts.append(e0.elapsed_time(e1) / 20)
 ts.sort()
 print(sys.argv[1], B, f"frames: lbs median {ts[4]:.4f} ms (min {ts[0]:.4f}, max {ts[-1]:.4f})")
+# parity of the loaded library against the oracle on the first 96 frames (development check of a variant build)
+o = H.oracle_model()
+n = min(B, 96)
+with torch.no_grad():
+    ref = o(global_orient=torch.tensor(p.global_orient[:n]), body_pose=torch.tensor(p.body_pose[:n]),
+            betas=torch.tensor(p.betas[:n]), transl=torch.tensor(p.transl[:n]))
+j, v = m.lbs(*args)
+print(f"   max |vertices - oracle| over {n} frames: {float((v[:n].cpu() - ref.vertices).abs().max()):.2e}, joints {float((j[:n].cpu() - ref.joints).abs().max()):.2e}")

@@ -1,0 +1,56 @@
+// Timing-only diagnostics of the LBS tile kernel (k2b_lbs.hip), kept OUT of the shipped translation unit: the kernel calls the
+// K2B_DIAG_* hooks, which are no-ops in the product build; tools/build_lbs_variants.sh compiles k2b_lbs.hip with
+//   -DK2B_LBS_DIAG_HEADER='"<repo>/tools/lbs_diag.h"' -DK2B_TILE_DIAG=<n>
+// into tools/libk2b_<name>.so.  Results of these builds are WRONG on purpose; they answer "what does this part cost".
+//   K2B_TILE_DIAG 1: every store goes to the dump row     2: only the first slice is ever filled (stale LDS afterwards)
+//   3: no MFMAs (fills, LDS reads, barriers, stores only)  5: stores land in the rows of the first 32 frames only (an
+//   L2-resident footprint: no HBM write stream)            6: s_memtime stamps of every slice of one tile (tools/dev_lbs_stamps.py)
+#pragma once
+#ifndef K2B_TILE_DIAG
+#define K2B_TILE_DIAG 0
+#endif
+
+#if K2B_TILE_DIAG == 2
+#define K2B_DIAG_SKIP_FILL(lq) ((lq) > 0)
+#else
+#define K2B_DIAG_SKIP_FILL(lq) false
+#endif
+
+#if K2B_TILE_DIAG == 5
+#define K2B_DIAG_STORE(f, ok) do { (f) &= 31; (ok) = true; } while (0)
+#elif K2B_TILE_DIAG == 1
+#define K2B_DIAG_STORE(f, ok) do { (f) = 0; (ok) = false; } while (0)
+#else
+#define K2B_DIAG_STORE(f, ok) ((void)0)
+#endif
+
+#if K2B_TILE_DIAG == 3
+// operands stay live (their LDS reads are kept), no matrix instruction
+#define K2B_DIAG_MFMA(x, y, c) ([&] { asm volatile("" ::"v"(x), "v"(y)); return (c); }())
+#else
+#define K2B_DIAG_MFMA(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0)
+#endif
+
+#if K2B_TILE_DIAG == 6
+// stamps of the workgroup's THIRD tile, all 8 waves, 8 per slice, kept in the unused 16 KiB of LDS behind the W image (no
+// vector-memory traffic, so the counted waits are undisturbed) and copied out at the end by the blocks 0 and 77
+#define K2B_DIAG_STAMP_DECL                                                                     \
+    unsigned* const diag_stamps = reinterpret_cast<unsigned*>(wimg + 8 * NGP * 256);             \
+    int diag_tile_no = 0
+#define K2B_DIAG_STAMP(slice, k)                                                                \
+    do { if (diag_tile_no == 2 && lane == 0) diag_stamps[(wave * 32 + (slice)) * 8 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define K2B_DIAG_TILE_DONE ++diag_tile_no
+#define K2B_DIAG_KERNEL_END                                                                     \
+    do {                                                                                        \
+        if (blockIdx.x == 0 || blockIdx.x == 77) {                                              \
+            wg_barrier();                                                                       \
+            unsigned* dst = reinterpret_cast<unsigned*>(a.dump) + 1024 + (blockIdx.x ? 2048 : 0); \
+            for (int i = threadIdx.x; i < 8 * 32 * 8; i += 512) dst[i] = diag_stamps[i];        \
+        }                                                                                       \
+    } while (0)
+#else
+#define K2B_DIAG_STAMP_DECL ((void)0)
+#define K2B_DIAG_STAMP(slice, k) ((void)0)
+#define K2B_DIAG_TILE_DONE ((void)0)
+#define K2B_DIAG_KERNEL_END ((void)0)
+#endif
