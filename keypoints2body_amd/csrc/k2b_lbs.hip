@@ -230,6 +230,7 @@ constexpr int kTileSlotBytes = 64 * 1024;
 #define K2B_TILE_CHUNK 8      // frame groups per L2 chunk of the tile walk
 #endif
 
+
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
