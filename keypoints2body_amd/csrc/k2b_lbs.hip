@@ -226,6 +226,9 @@ constexpr int kTileSlotBytes = 64 * 1024;
 #define K2B_DIAG_TILE_DONE ((void)0)
 #define K2B_DIAG_KERNEL_END ((void)0)
 #endif
+#ifndef K2B_TILE_AHEAD
+#define K2B_TILE_AHEAD(NKT) ((NKT) <= 3)
+#endif
 #ifndef K2B_TILE_CHUNK
 #define K2B_TILE_CHUNK 8      // frame groups per L2 chunk of the tile walk
 #endif
@@ -392,18 +395,17 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 *reinterpret_cast<float3v*>(dst) = x;
             }
     };
-    floatx4 pend[2][3];           // loader waves: outputs of the previous slice, stored at the top of the next one
-    int pend_f = 0, pend_vg = 0;
-    bool pend_valid = false;
-    bool stored = false;
-    auto slice_top = [&]() {      // loader waves only: fills first (a wave's memory requests are taken in order, and the fills are
-                                  // what the next slice waits for), then the held outputs
+    // Every wave stores a unit's outputs at the end of the unit.  (Round 2 let the loader waves hold theirs across the barrier and
+    // store them behind the next slice's fills; with the joint copies in the kernel those 24 registers push both instantiations
+    // into scratch - the SMPL-X one spilled 25 registers at the tile boundaries - and without the hold the launch is 3-7 % faster
+    // for SMPL and 7 % for SMPL-X: round 3 measurements, tools/build_lbs_variants.sh hold:"-DK2B_TILE_HOLD=1" no longer exists.)
+    bool stored = false;          // loader waves: eight stores of this slice are in flight behind its fills
+    auto slice_top = [&]() {      // loader waves only: the fills of the next slice
         issue();
-        stored = pend_valid;
-        if (pend_valid) { emit_stores(pend, pend_f, pend_vg); pend_valid = false; }
+        stored = false;
     };
-    auto loader_wait = [&]() {    // the fills have landed; the eight stores behind them may fly on (joint copies stored later in the
-                                  // slice are younger still: "at most 8 outstanding" keeps meaning "every fill has landed")
+    auto loader_wait = [&]() {    // the fills have landed; the eight stores behind them may fly on (joint copies are younger still:
+                                  // "at most 8 outstanding" keeps meaning "every fill has landed")
         if (stored) wait_vmcnt<8>(); else wait_vmcnt<0>();
     };
 
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                 // (large trees: 2 x NKT fragment registers of look-ahead do not fit beside the resident W fragments - the SMPL-X
                 //  instantiation spilled 24 registers, and every scratch reload is a vmcnt(0) wait in the middle of the request
                 //  stream - so there the fragments of an entry are read right before its MFMAs; the SIMD partner covers the wait)
-                constexpr bool AHEAD = NKT <= 3;
+                constexpr bool AHEAD = K2B_TILE_AHEAD(NKT);
                 half8 af[AHEAD ? 2 : 1][NKT];
                 floatx4 t[2][2];
                 if (AHEAD) {
@@ -583,15 +585,8 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
                                 }
                             }
                     }
-                    if (loader) {
-#pragma unroll
-                        for (int v = 0; v < 2; ++v)
-#pragma unroll
-                            for (int r = 0; r < 3; ++r) pend[v][r] = out[v][r];
-                        pend_f = fbase0; pend_vg = cw.vg; pend_valid = true;
-                    } else {
-                        emit_stores(out, fbase0, cw.vg);
-                    }
+                    emit_stores(out, fbase0, cw.vg);
+                    stored = true;               // (loaders: these eight stores are younger than the slice's fills)
                 }
                 stamp(KX + u * NTS + ts, 3);
                 if (loader) loader_wait();
@@ -604,7 +599,6 @@ __global__ __launch_bounds__(512) void k2b_lbs_tile_kernel(const TileArgs a) {
         cw.next();
         K2B_DIAG_TILE_DONE;
     }
-    if (loader && pend_valid) emit_stores(pend, pend_f, pend_vg);
     wait_vmcnt<0>();
     K2B_DIAG_KERNEL_END;
 }
