@@ -696,6 +696,9 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
     a.opt_mask = cfg->optimize_mask & 15;
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;
+    if (cfg->debug_launch_shape < 0 || cfg->debug_launch_shape > 3)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: debug_launch_shape=%d must be 0..3", cfg->debug_launch_shape);
+    a.debug_shape = cfg->debug_launch_shape <= 2 ? cfg->debug_launch_shape : 0;   // tree kernel: 1 = plain, 2 = component waves
     if (!vsel.empty()) {
         if (num_kinematic == 0)
             return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: at least one kinematic joint (model index < %d) must be among the targets", J);

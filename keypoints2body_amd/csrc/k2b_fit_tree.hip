@@ -59,16 +59,94 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int J = a.num_joints, NB = a.num_shape, Dv = a.prior_dims;
-    const int tw = blockDim.x >> 6;                                // frames (waves) of this workgroup: 1..TW, by batch size
-    const int fr_raw = blockIdx.x * tw + wave;
-    const bool frame_ok = fr_raw < a.num_frames;
+    // Two shapes.  Plain: every wave carries a frame, and between two barriers every wave also runs its share of the
+    // mixture's components for all frames of the workgroup.  Component-wave shape (<= 4 frames per CU, i.e. at most one
+    // frame per SIMD): four EXTRA waves - one per SIMD, beside the frame wave - own two components each, keep their
+    // fragments in registers for the whole launch (no fragment image in LDS) and evaluate them for every frame WHILE the frame
+    // waves run kinematics and the backward; the frame waves only wait for y' and q before the priors.  In the plain shape the
+    // component phase sat between the barriers as a latency chain (fragment reads, six dependent MFMAs per tile, LDS round
+    // trips: 44 % of an iteration at 1024 frames).
+    const int ncw = a.comp_waves;                                  // 0 or 4
+    const int tw = (blockDim.x >> 6) - ncw;                        // frames (waves) of this workgroup: 1..TW, by batch size
+    const bool comp_role = wave >= tw;
+    const int fr_raw = blockIdx.x * tw + (comp_role ? 0 : wave);
+    const bool frame_ok = !comp_role && fr_raw < a.num_frames;
     const int fr = frame_ok ? fr_raw : a.num_frames - 1;           // idle waves shadow the last frame and write nothing
 
     // ---- prior image -> LDS (whole workgroup) ---------------------------------------------------------------------------
-    for (int i = threadIdx.x; i < TMG * 16 * 64; i += blockDim.x)
-        reinterpret_cast<float4*>(tlds)[i] = reinterpret_cast<const float4*>(a.pfrag)[i];
+    if (ncw == 0)
+        for (int i = threadIdx.x; i < TMG * 16 * 64; i += blockDim.x)
+            reinterpret_cast<float4*>(tlds)[i] = reinterpret_cast<const float4*>(a.pfrag)[i];
     for (int i = threadIdx.x; i < TMG * 64; i += blockDim.x) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
     __syncthreads();
+
+    if (comp_role) {
+        // ---- component waves: components cw and cw + 4, fragments resident in registers (128 VGPRs) ------------------------------
+        if (!(a.pose_prior_w * a.pose_prior_w > 0.f)) return;      // no mixture term: the frame waves take no barriers either
+        const int cw = wave - tw;
+        const int cn = lane & 15, cg = lane >> 4;                  // MFMA lane: column (frame slot) and k / row group
+        const int cslot = cn < tw ? cn : tw - 1;
+        half8 fh[2][4][2], fl[2][4][2];                            // [own component][row tile][k-step]
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const half8* fi = reinterpret_cast<const half8*>(a.pfrag) + (size_t)(((cw + 4 * o) * 4 + t) * 4) * 64 + lane;
+                fh[o][t][0] = fi[0]; fh[o][t][1] = fi[64]; fl[o][t][0] = fi[128]; fl[o][t][1] = fi[192];
+            }
+        const int steps = CHAIN ? a.chain_len : 1;
+        for (int step = 0; step < steps; ++step) {
+            const int nit = step == 0 ? a.num_iters : a.chain_iters;
+            for (int it = 0; it < nit; ++it) {
+                __syncthreads();                                   // theta_v of every frame published
+                const half8 bh0 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 8 * cg);
+                const half8 bh1 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 32 + 8 * cg);
+                const half8 bl0 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 64 + 8 * cg);
+                const half8 bl1 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 96 + 8 * cg);
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int c = cw + 4 * o;
+                    // the four row tiles are independent chains: issued step-major, small terms first (as in the plain shape)
+                    floatx4 acc[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[o][t][0], bh0, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[o][t][1], bh1, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[o][t][0], bl0, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[o][t][1], bl1, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[o][t][0], bh0, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[o][t][1], bh1, acc[t], 0, 0, 0);
+                    const float inv_scale = a.inv_scale[c];
+                    float qp = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r0 = 16 * t + 4 * cg;
+                        const floatx4 th4 = *reinterpret_cast<const floatx4*>(sTh + cslot * 64 + r0);
+                        const floatx4 mu4 = *reinterpret_cast<const floatx4*>(sMu + c * 64 + r0);
+                        const floatx4 h4 = *reinterpret_cast<const floatx4*>(sH + c * 64 + r0);
+                        const floatx4 b4 = *reinterpret_cast<const floatx4*>(sB + c * 64 + r0);
+                        floatx4 y;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            y[i] = acc[t][i] * inv_scale + h4[i];
+                            qp += (th4[i] - mu4[i]) * (y[i] + b4[i]);
+                        }
+                        *reinterpret_cast<floatx4*>(sY + (cslot * TMG + c) * 64 + r0) = y;
+                    }
+                    qp = pair_sum32(qp);
+                    qp = pair_sum16(qp);
+                    sQ[cslot * TMG + c] = qp;
+                }
+                asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));   // (B fragments live past the last MFMA, see k2b_fit.hip)
+                __syncthreads();                                   // y' and q published
+            }
+        }
+        return;
+    }
 
     // ---- per-lane constants ---------------------------------------------------------------------------------------------
     const int* tb = a.tab + lane * 8;
@@ -166,6 +244,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             sTh16[wave * 128 + lane] = hh;
             sTh16[wave * 128 + 64 + lane] = (_Float16)(thv - (float)hh);
             __syncthreads();
+          if (ncw == 0) {
             // component role: y' = A theta_v + h and q = d . (y' + b) of the components w, w + tw, ... for every frame slot
             const half8 bh0 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 8 * cg);
             const half8 bh1 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 32 + 8 * cg);
@@ -206,6 +285,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             // keep the B fragments live past the last MFMA (ROCm 7.2 register allocation, see k2b_fit.hip)
             asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
             __syncthreads();
+          }
         }
         // ---- rest offset from the parent: d = dt + dd . shape -------------------------------------------------------------
         float dx = dtx, dy = dty, dz = dtz;
@@ -297,6 +377,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         float gv = 0.f, lv = 0.f;                // gradient and loss contributions in prior layout
         float lpr = 0.f;
         if (use_gmm) {
+            if (ncw != 0) __syncthreads();       // component-wave shape: y' and q arrive while this wave ran the tree
             float best = 3.0e38f;
             int bm = 0;
 #pragma unroll
@@ -370,17 +451,21 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
 
 }  // namespace
 
-hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream) {
-    if (a.num_frames <= 0) return hipSuccess;
-    if (a.num_joints > 64 || a.num_shape > 32 || a.prior_dims > 64 || a.num_gauss > TMG) return hipErrorInvalidValue;
+hipError_t launch_fit_tree(const FitTreeArgs& a_in, hipStream_t stream) {
+    if (a_in.num_frames <= 0) return hipSuccess;
+    if (a_in.num_joints > 64 || a_in.num_shape > 32 || a_in.prior_dims > 64 || a_in.num_gauss > TMG) return hipErrorInvalidValue;
     const size_t lds = (size_t)(TMG * 16 * 64 * 4 + 3 * TMG * 64 + 2 * TW * 64 + TW * TMG * 64 + TW * TMG) * sizeof(float);
     // frames per workgroup: enough to cover the batch with one workgroup per CU (up to 8: two waves per SIMD); small
     // batches get fewer waves per CU, so that every SIMD hosts at most one frame and all CUs work
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int tw = (a.num_frames + cus - 1) / cus;
+    int tw = (a_in.num_frames + cus - 1) / cus;
     tw = tw < 1 ? 1 : (tw > TW ? TW : tw);
-    const dim3 grid((a.num_frames + tw - 1) / tw), block(64 * tw);
+    FitTreeArgs a = a_in;
+    // at most one frame per SIMD: four component waves ride along (one per SIMD) and take the mixture off the frame waves
+    a.comp_waves = a.debug_shape == 1 ? 0 : ((tw <= 4 || a.debug_shape == 2) ? 4 : 0);
+    if (a.debug_shape == 2 && tw > 4) tw = 4;
+    const dim3 grid((a.num_frames + tw - 1) / tw), block(64 * (tw + a.comp_waves));
     hipError_t e;
 #define K2B_TREE(NS_, CH_)                                                                                             \
     do {                                                                                                               \

@@ -101,6 +101,8 @@ struct FitTreeArgs {
     int angle_index[4];
     float angle_sign[4];
     int chain_len, chain_iters;  // warm-start chain: num_frames SEQUENCES of chain_len frames each (<= 1: independent frames)
+    int comp_waves;              // set by launch_fit_tree: 4 = the mixture runs on four dedicated component waves (<= 4 frames per CU)
+    int debug_shape;             // 0 = chosen by the batch size; 1 = force the plain shape, 2 = force the component-wave shape (tests)
 };
 hipError_t launch_fit_tree(const FitTreeArgs& a, hipStream_t stream);
 

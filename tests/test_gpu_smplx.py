@@ -23,9 +23,10 @@ def pack(d, prefix, rows=slice(None)):
     return d[prefix + "global_orient"][rows], pose, shape, d[prefix + "transl"][rows]
 
 
-def native_fit_x(d, num_iters):
+def native_fit_x(d, num_iters, shape=0):
     from keypoints2body_amd import native
     cfg = native.default_fit_config()
+    cfg.debug_launch_shape = shape                  # tree kernel: 0 = by batch size, 1 = plain, 2 = component waves
     cfg.num_iters = int(num_iters)
     cfg.pose_preserve_weight = 5.0 if int(d["seq_ind"]) > 0 else 0.0
     cfg.freeze_betas = int(d["freeze_betas"])
@@ -77,6 +78,20 @@ def test_smplx_fit_matches_reference_golden(case):
     if int(d["freeze_betas"]):
         assert torch.equal(out["betas"][:, :10].cpu(), torch.tensor(d["init_betas"]))
     print(f"smplx {case}: worst parameter deviation over the trace = {worst:.2e}")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_smplx_both_shapes_of_the_tree_kernel_agree_and_match_the_golden(case):
+    """The tree kernel runs the mixture either inside every frame wave (plain shape: more than four frames per CU) or on four
+    dedicated component waves beside the frame waves (at most four frames per CU - every small case above).  Same arithmetic
+    in the same order: the two shapes must agree to the last bit, and each reproduces the reference's end state."""
+    d = H.load_smplx_case(case)
+    plain, comp = native_fit_x(d, d["num_iters"], shape=1), native_fit_x(d, d["num_iters"], shape=2)
+    go, pose, shape, tr = pack(d, "out_")
+    for key, want in (("global_orient", go), ("body_pose", pose), ("betas", shape), ("transl", tr)):
+        assert torch.equal(plain[key], comp[key]), (case, key)
+        assert np.abs(plain[key].cpu().numpy() - want).max() < PARAM_TOL, (case, key)
+    assert torch.equal(plain["loss"], comp["loss"])
 
 
 def test_smplx_fitter_api_returns_smplx_data():
