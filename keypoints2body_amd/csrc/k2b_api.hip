@@ -16,6 +16,10 @@
 #include "k2b_internal.h"
 
 
+#ifndef K2B_LBS_STREAM
+#define K2B_LBS_STREAM 1      // 0: development builds that keep the tile kernel for 17-24 joint models (A/B timing)
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -75,9 +79,11 @@ struct k2b_model {
     struct VertexSet {
         k2b::k2b_half *pdh = nullptr, *pdl = nullptr;
         k2b::k2b_half* w2 = nullptr;                         // W in the tile kernel's group layout (k2b_internal.h, TileArgs)
-        int v_tiles = 0, num = 0;
+        k2b::k2b_half *spd = nullptr, *sw = nullptr;         // stream kernel's Pd / W (k2b_internal.h, StreamArgs), or null
+        int v_tiles = 0, num = 0, nv16 = 0;
     } mesh, extra;
     bool joints_in_mesh = false;                             // every extra joint's vertex is tagged in mesh.w2 (no gather launch)
+    bool stream = false;                                     // 17-24 joints and 7 pose k-steps: the stream kernel skins this model
     // tables of the tree fit kernel (any J <= 64), lane order = DFS pre-order
     float *tt_dt = nullptr, *tt_dd = nullptr;
     int *tt_tab = nullptr, *tt_anc = nullptr;
@@ -184,6 +190,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         const int KX = ((P + NB + 2 + 31) / 32) * 2;   // even: the kernel stages 32-deep slices
         m->k_steps_x = KX;
         m->groups_a = k2b::tile_groups_a(J);
+        m->stream = K2B_LBS_STREAM && m->groups_a == 3 && KX == 2 * k2b::kStreamKSteps;
         HIP_TRY(hipMalloc((void**)&m->dump, 64 * 1024));     // 64 x 3 floats used; the rest is room for diagnostic builds
         // tag[i] = 1 + e when vertex i of the set is the vertex of output joint J + e (mesh set only), else 0
         auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids, const std::vector<int>& tag) -> int {
@@ -233,6 +240,34 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                     if (i < n && !tag.empty() && tag[i]) rowp[(size_t)(2 * GA + 1) * 128] = (k2b::k2b_half)(float)tag[i];   // ZERO group: joint tag
                 }
             hipError_t e;
+            if (m->stream) {
+                // stream kernel: Pd [k-step][16-vertex tile][coord][hi | lo] and W [16-vertex tile][3 fragments], 1 KiB pieces in
+                // MFMA operand order (lane = row + 16 k-group, 8 halfs); vertex tiles padded to whole 128-vertex groups
+                const int nv16 = (n + 127) / 128 * 8;
+                vs.nv16 = nv16;
+                std::vector<k2b::k2b_half> spd((size_t)k2b::kStreamKSteps * nv16 * 6 * 512, (k2b::k2b_half)0.f), sw((size_t)nv16 * 3 * 512, (k2b::k2b_half)0.f);
+                for (int i = 0; i < n; ++i) {
+                    const int v16 = i >> 4, r = i & 15;
+                    for (int c = 0; c < 3; ++c)
+                        for (int k = 0; k < KX * 16; ++k) {      // the split values already sit in pdh / pdl: same k, same scale
+                            const size_t src = k2b::frag_elem(((size_t)(k >> 4) * 3 + c) * vs.v_tiles + (i >> 5), k, i);
+                            const size_t dst = ((((size_t)(k >> 5) * nv16 + v16) * 3 + c) * 2) * 512 + (size_t)((((k >> 3) & 3) * 16 + r) * 8 + (k & 7));
+                            spd[dst] = pdh[src];
+                            spd[dst + 512] = pdl[src];
+                        }
+                    k2b::k2b_half* wt = sw.data() + (size_t)v16 * 3 * 512;
+                    for (int j = 0; j < J; ++j) {
+                        const float w = lbs_weights[(size_t)ids[i] * J + j];
+                        const k2b::k2b_half hi = (k2b::k2b_half)w;
+                        const size_t o = (size_t)(((j >> 3) * 16 + r) * 8 + (j & 7));
+                        wt[o] = hi; wt[512 + o] = hi; wt[1024 + o] = (k2b::k2b_half)(w - (float)hi);
+                    }
+                    for (int k = 0; k < 3; ++k) wt[(size_t)((3 * 16 + r) * 8 + k)] = (k2b::k2b_half)1.f;          // fragment 0, group 3: ONES
+                    if (!tag.empty() && tag[i]) wt[512 + (size_t)((3 * 16 + r) * 8)] = (k2b::k2b_half)(float)tag[i];   // fragment 1, group 3: tag
+                }
+                if ((e = upload(&vs.spd, spd.data(), spd.size())) != hipSuccess) return (int)e;
+                if ((e = upload(&vs.sw, sw.data(), sw.size())) != hipSuccess) return (int)e;
+            }
             if ((e = upload(&vs.w2, w2.data(), w2.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdh, pdh.data(), pdh.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdl, pdl.data(), pdl.size())) != hipSuccess) return (int)e;
@@ -370,7 +405,8 @@ void k2b_model_destroy(k2b_model* m) {
     float* fl[] = {m->v_template, m->shapedirs, m->posedirs, m->j_regressor, m->lbs_weights, m->j_template,
                    m->j_dirs, m->dt, m->dd};
     for (float* p : fl) if (p) (void)hipFree(p);
-    k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->extra.pdh, m->extra.pdl, m->wsXh, m->wsXl, m->mesh.w2, m->extra.w2, m->wsA2};
+    k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->extra.pdh, m->extra.pdl, m->wsXh, m->wsXl, m->mesh.w2, m->extra.w2, m->wsA2,
+                           m->mesh.spd, m->mesh.sw, m->extra.spd, m->extra.sw};
     if (m->dump) (void)hipFree(m->dump);
     if (m->tt_dt) (void)hipFree(m->tt_dt);
     if (m->tt_dd) (void)hipFree(m->tt_dd);
@@ -975,8 +1011,18 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     if (m->groups_a != 3 && m->groups_a != 7)
         return fail(K2B_ERR_UNSUPPORTED, "k2b_lbs: %d joints; the vertex kernel is built for 17-24 (SMPL) and 49-56 (SMPL-H / SMPL-X) joints", m->J);
     pa.xh = m->wsXh; pa.xl = m->wsXl; pa.a2 = m->wsA2; pa.joints_out = joints_out;
+    pa.a2_stream_order = m->stream ? 1 : 0;
     HIP_TRY(k2b::launch_pose_setup(pa, stream));
     auto skin = [&](const k2b_model::VertexSet& vs, float* out, int stride, int row0, float* joint_copies) -> hipError_t {
+        if (m->stream) {
+            k2b::StreamArgs sa{};
+            sa.xh = m->wsXh; sa.xl = m->wsXl; sa.a2 = m->wsA2; sa.pd = vs.spd; sa.w = vs.sw;
+            sa.f32_tiles = bpad / 32; sa.nv16 = vs.nv16;
+            sa.num_frames = B; sa.num_out = vs.num; sa.out = out; sa.out_stride = stride; sa.out_row0 = row0;
+            sa.dump = m->dump;
+            sa.joints_out = joint_copies; sa.joints_stride = m->J + m->E; sa.joints_row0 = m->J;
+            return k2b::launch_skin_stream(sa, device_cus(), stream);
+        }
         k2b::TileArgs ta{};
         ta.xh = m->wsXh; ta.xl = m->wsXl; ta.a2 = m->wsA2; ta.pdh = vs.pdh; ta.pdl = vs.pdl; ta.w2 = vs.w2;
         ta.groups_a = m->groups_a; ta.k_steps_x = m->k_steps_x; ta.f_tiles = bpad / 32; ta.v_tiles = vs.v_tiles;

@@ -129,6 +129,7 @@ struct PoseArgs {
     const float *go, *bp, *be, *tr;  // tr may be null
     k2b_half *xh, *xl;         // pieces [k_steps_x][frames_padded / 32]
     k2b_half* a2;              // group layout of the tile kernel (see TileArgs)
+    int a2_stream_order;       // 1: k-groups of an entry in the stream kernel's order hi.. | PAD | lo.. | ZERO (see StreamArgs)
     float* joints_out;         // [B][num_out_joints][3] (first J rows written) or null
 };
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream);
@@ -164,6 +165,28 @@ struct TileArgs {
     int num_wgs;                 // grid size (a multiple of 8), set by the launcher
 };
 hipError_t launch_skin_tiles(const TileArgs& a, int num_cus, hipStream_t stream);
+
+// ---- stream kernel (k2b_lbs_stream.hip): the same tile for 17-24 joints and 7 pose k-steps, Pd global -> registers ------------
+// Operands (1 KiB pieces = 64 lanes x 8 halfs in v_mfma_f32_16x16x32_f16 operand order: lane = row + 16 k-group):
+//   X   as for the tile kernel
+//   A   [16-frame tile][entry 12][fragment 2]: fragment 0 = k-groups hi_0 hi_1 hi_2 PAD, fragment 1 = lo_0 lo_1 lo_2 ZERO
+//       (the pose set-up writes this group order with PoseArgs::a2_stream_order)
+//   Pd  [k-step 7][16-vertex tile][coordinate 3][hi | lo]
+//   W   [16-vertex tile][3]: [hi | ONES], [hi | tag], [lo | 0]   (tag: 1 + output joint of the vertex, first half of the group)
+constexpr int kStreamKSteps = 7;
+struct StreamArgs {
+    const k2b_half *xh, *xl, *a2, *pd, *w;
+    int f32_tiles;               // 32-frame tiles (frames padded / 32)
+    int nv16;                    // 16-vertex tiles of the padded vertex set, a multiple of 8
+    int num_frames, num_out;
+    float* out;
+    int out_stride, out_row0;
+    float* dump;
+    float* joints_out;           // see TileArgs
+    int joints_stride, joints_row0;
+    int num_wgs;
+};
+hipError_t launch_skin_stream(const StreamArgs& a, int num_cus, hipStream_t stream);
 hipError_t launch_gather_joints(const float* verts, const int* ids, float* joints, int num_frames, int V, int J, int E,
                                 hipStream_t stream);
 

@@ -172,11 +172,11 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
             if (c < 12 * 2 * GA) {
                 const int e = c / (2 * GA), r = c % (2 * GA), lo = r >= GA, g = lo ? r - GA : r;
                 v = *reinterpret_cast<const uint4*>((lo ? &sAl[e][0] : &sAh[e][0]) + 8 * g);
-                grp = (size_t)e * NGP + r;
+                grp = (size_t)e * NGP + (a.a2_stream_order ? (lo ? GA + 1 + g : g) : r);
             } else {
                 const int r3 = c - 12 * 2 * GA;
                 v = *reinterpret_cast<const uint4*>(&sTp[r3][0]);
-                grp = (size_t)(4 * r3 + 3) * NGP + 2 * GA;
+                grp = (size_t)(4 * r3 + 3) * NGP + (a.a2_stream_order ? GA : 2 * GA);
             }
             *reinterpret_cast<uint4*>(base + grp * 16 * 8) = v;
         }

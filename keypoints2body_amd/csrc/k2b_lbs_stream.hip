@@ -1,0 +1,292 @@
+// k2b_lbs_stream.hip — vertex skinning for 17-24 joint models (SMPL), round-3 design for gfx950.
+//
+// Same arithmetic as the tile kernel of k2b_lbs.hip (two GEMMs over frames x vertices on v_mfma_f32_16x16x32_f16, operands
+// as f16 hi/lo pairs, v = T [v_posed; 1] + t; reference seam: the final forward of world_space.py:258-278, smplx's
+// SMPL.forward), and the same 128 frames x 128 vertices per persistent workgroup.  What changed is how the operands travel:
+//
+//   * a wave owns 16 vertices x 128 frames (eight 16 x 16 accumulator tiles per coordinate).  Its share of the big
+//     B operand Pd (posedirs | shapedirs | template, 48 of the 64 KiB a 32-deep k-step needs) is private to it, so it goes
+//     global -> REGISTERS with plain 16-byte loads, two k-steps ahead, and never touches LDS or a barrier;
+//   * the frame-side operand X of the WHOLE tile (7 k-steps x 16 KiB) is resident in LDS: the pose phase has NO barrier at all,
+//     waves drift apart and the stores of one wave overlap the matrix work of another;
+//   * X of the next tile is fetched by LDS-DMA during the transform phase, one k-step per 16-frame unit, the transform
+//     operand A in a two-slot ring of 24 KiB units: one workgroup barrier per unit, 8 per tile (tile kernel: 11, and 64 KiB
+//     of fills behind each);
+//   * per entry of the 3 x 4 transform the two A fragments [hi | t] and [lo | 0] are read ONCE and meet three resident W
+//     fragments [hi | 1], [hi | tag], [lo | 0]: two LDS reads for three MFMAs.
+// Every vector-memory wait is a counted s_waitcnt with a compile-time count (the issue order of a wave is fixed; loads, LDS-DMA
+// and stores retire in order), so the loads the wave does not need yet stay in flight.
+//
+// LDS: 7 x 16 KiB (X) + 2 x 24 KiB (A units) = 160 KiB.  Built for 7 k-steps (9 (J - 1) + NB + 2 <= 224: SMPL with up to 15
+// shape coefficients); everything else runs the tile kernel.
+#include <hip/hip_fp16.h>
+
+#include "k2b_internal.h"
+
+namespace k2b {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) float3v { float x, y, z; };
+
+constexpr int SKX = kStreamKSteps;                 // 32-deep k-steps of the pose GEMM
+constexpr int kXBytes = SKX * 16 * 1024;
+constexpr int kUnitBytes = 24 * 1024;              // A operand of one 16-frame unit: 12 entries x 2 fragments
+constexpr int CHUNK = 8;                           // frame groups per L2 chunk of the tile walk (as the tile kernel)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// 16-byte load global -> register through a scalar base and a per-lane byte offset; the result is only valid behind a
+// counted wait that names the register (pd_ready / below)
+template <int OFF>
+__device__ __forceinline__ void gload16(half8& dst, unsigned lane_off, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(sbase), "n"(OFF) : "memory");
+}
+
+struct Walk {                  // (frame group, vertex group) tiles of this workgroup, XCD-aware: see TileWalk in k2b_lbs.hip
+    int vgroups, fgroups, item_lo, item_hi, nx, t, fg, vg;
+    bool valid;
+    __device__ void init(int vgroups_, int fgroups_, int block, int nblocks) {
+        vgroups = vgroups_; fgroups = fgroups_;
+        const int items = ((fgroups + CHUNK - 1) / CHUNK) * vgroups, x = block & 7;
+        item_lo = (int)((long long)items * x / 8); item_hi = (int)((long long)items * (x + 1) / 8);
+        nx = nblocks >> 3;
+        t = (block >> 3) - nx;
+        next();
+    }
+    __device__ void next() {
+        for (;;) {
+            t += nx;
+            const int item = item_lo + t / CHUNK;
+            if (item >= item_hi) { valid = false; return; }
+            const int c = item / vgroups;
+            fg = c * CHUNK + t % CHUNK; vg = item - c * vgroups;
+            if (fg < fgroups) { valid = true; return; }
+        }
+    }
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [7][16 KiB] X | [2][24 KiB] A units
+    unsigned char* const aslots = lds + kXBytes;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = lane & 15, g = lane >> 4;                 // MFMA operand lane: row of the 16-row tile, k-group
+    const int f32tiles = a.f32_tiles, f16tiles = 2 * f32tiles, nv16 = a.nv16;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    Walk cw;
+    cw.init(nv16 >> 3, (f32tiles + 3) >> 2, blockIdx.x, a.num_wgs);
+    if (!cw.valid) return;
+
+    // ---- issue helpers (all addresses wave-uniform + lane x 16 B) ----------------------------------------------------------
+    // X of k-step ks: 16 pieces [k-half 2][32-frame tile 4][hi | lo]; wave w moves (k-half w >> 2, frame tile w & 3), hi and lo
+    auto issue_x = [&](int fg, int ks) {
+        const int kh = wave >> 2, ft = wave & 3;
+        int ftc = fg * 4 + ft;
+        ftc = ftc < f32tiles ? ftc : f32tiles - 1;
+        const size_t o = ((size_t)(2 * ks + kh) * f32tiles + ftc) * 512 + lane * 8;
+        unsigned char* dst = lds + ks * 16384 + (kh * 8 + ft * 2) * 1024;
+        __builtin_amdgcn_global_load_lds(a.xh + o, dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(a.xl + o, dst + 1024, 16, 0, 0);
+    };
+    // A of one 16-frame unit: 24 contiguous pieces [entry 12][fragment 2]; wave w moves pieces 3 w .. 3 w + 2
+    auto issue_a = [&](int f16, int slot) {
+        f16 = f16 < f16tiles ? f16 : f16tiles - 1;
+        const k2b_half* src = a.a2 + ((size_t)f16 * 24 + 3 * wave) * 512 + lane * 8;
+        unsigned char* dst = aslots + slot * kUnitBytes + 3 * wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds(src + i * 512, dst + i * 1024, 16, 0, 0);
+    };
+    // Pd of this wave's 16 vertices for k-step ks: 6 consecutive KiB [coordinate 3][hi | lo]
+    auto load_pd = [&](half8 (&buf)[3][2], int vg, int ks) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.pd + ((size_t)ks * nv16 + vg * 8 + wave) * 6 * 512) + 3072;
+        gload16<-3072>(buf[0][0], lane16, base); gload16<-2048>(buf[0][1], lane16, base);
+        gload16<-1024>(buf[1][0], lane16, base); gload16<0>(buf[1][1], lane16, base);
+        gload16<1024>(buf[2][0], lane16, base);  gload16<2048>(buf[2][1], lane16, base);
+    };
+#define K2B_PD_READY(N, b)                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]) : "n"(N) : "memory")
+
+    const int lx = (g >> 1) * 8192 + (g & 1) * 512 + row * 16;      // lane part of an X fragment address inside a k-step
+    const int la = g * 256 + row * 16;                               // lane part of an A fragment address inside a piece
+    const float inv_scale = 1.0f / kPdScale;
+    float* const dump = a.dump + lane * 3;
+    auto rd = [&](const unsigned char* p) -> half8 { return *reinterpret_cast<const half8*>(p); };
+
+    // ---- prologue: everything the first tile needs ------------------------------------------------------------------------
+    half8 pb0[3][2], pb1[3][2], pb2[3][2];      // Pd buffers: k-step ks lives in buffer ks % 3
+    half8 wf[3];                                // W fragments of this wave's 16 vertices: [hi | 1], [hi | tag], [lo | 0]
+#pragma unroll
+    for (int ks = 0; ks < SKX; ++ks) issue_x(cw.fg, ks);            // 14 fills
+    issue_a(cw.fg * 8, 0);                                          // 3 fills
+    load_pd(pb0, cw.vg, 0);                                         // 6 loads
+    load_pd(pb1, cw.vg, 1);                                         // 6 loads
+    wait_vmcnt<12>();                                               // X and the first A unit of this wave have landed
+    wg_barrier();
+
+    bool first = true;
+    while (cw.valid) {
+        Walk nw = cw;
+        nw.next();
+        const int nfg = nw.valid ? nw.fg : cw.fg, nvg = nw.valid ? nw.vg : cw.vg;   // (no next tile: the same addresses again,
+                                                                                     //  so that the counted waits keep their counts)
+        floatx4 vp[8][3];         // [16-frame tile][coordinate]
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vp[f][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- pose phase: v_posed * kPdScale = X . Pd, no barrier -------------------------------------------------------------
+        auto kstep = [&](int ks, const half8 (&pd)[3][2]) {
+            const unsigned char* xb = lds + ks * 16384 + lx;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const half8 xh = rd(xb + (f >> 1) * 2048 + (f & 1) * 256), xl = rd(xb + (f >> 1) * 2048 + 1024 + (f & 1) * 256);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, pd[c][0], vp[f][c], 0, 0, 0);
+                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, pd[c][1], vp[f][c], 0, 0, 0);
+                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, pd[c][0], vp[f][c], 0, 0, 0);
+                }
+            }
+        };
+        // younger than the awaited loads at each wait (in issue order): see the table in DESIGN.md 4.2
+        if (first) K2B_PD_READY(6, pb0);               // k-step 0: behind the prologue only k-step 1 is younger,
+        else K2B_PD_READY(7, pb0);                     // later the A fills + stores of the previous tile's last unit
+        first = false;
+        {                                              // W fragments of this tile's vertices, Pd two k-steps ahead
+            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w + ((size_t)cw.vg * 8 + wave) * 3 * 512);
+            gload16<0>(wf[0], lane16, wbase); gload16<1024>(wf[1], lane16, wbase); gload16<2048>(wf[2], lane16, wbase);
+        }
+        load_pd(pb2, cw.vg, 2);
+        kstep(0, pb0);
+        K2B_PD_READY(9, pb1);                          // k-step 1: W (3) and k-step 2 (6) are younger
+        load_pd(pb0, cw.vg, 3);
+        kstep(1, pb1);
+        K2B_PD_READY(6, pb2);
+        load_pd(pb1, cw.vg, 4);
+        kstep(2, pb2);
+        K2B_PD_READY(6, pb0);
+        load_pd(pb2, cw.vg, 5);
+        kstep(3, pb0);
+        K2B_PD_READY(6, pb1);
+        load_pd(pb0, cw.vg, 6);
+        kstep(4, pb1);
+        K2B_PD_READY(6, pb2);
+        load_pd(pb1, nvg, 0);                          // the next tile's first two k-steps ride through the transform phase
+        kstep(5, pb2);
+        K2B_PD_READY(6, pb0);
+        load_pd(pb2, nvg, 1);
+        kstep(6, pb0);
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vp[f][c] *= inv_scale;
+
+        // ---- transform phase: one 16-frame unit at a time ---------------------------------------------------------------------
+        // this wave's vertex, and the output joint it may be (tag = 1 + index, first half of the padding group of fragment 1)
+        const int v = (cw.vg * 8 + wave) * 16 + row;
+        const bool okv = v < a.num_out;
+        int jrow = 0;
+        bool has_joint = false;
+        float* const orow = a.out + ((size_t)a.out_row0 + v) * 3;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // A of this unit has landed (each wave waits for its own pieces, the barrier collects them); what may stay in flight is
+            // younger: the previous unit's 2 X fills + 4 stores (unit 0: the 12 Pd loads for the next tile; unit 7: stores only,
+            // because the last X fills must be visible to every wave before the next pose phase)
+            if (u == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2])::"memory");   // (W: loaded at k-step 0)
+            else if (u == 7) wait_vmcnt<4>(); else wait_vmcnt<6>();
+            wg_barrier();
+            if (u == 0 && a.joints_out) {              // (W fragments are long there: they are older than everything waited for)
+                const float tg = (float)wf[1][0];      // lanes g == 3 hold the padding group of their row
+                jrow = (int)__shfl(tg, 48 + row, 64);
+                has_joint = __builtin_amdgcn_ballot_w64(jrow != 0) != 0;
+            }
+            // behind the barrier the other slot and (after unit 0) the X region are free: next unit's A, next tile's X k-step u
+            if (u < 7) { issue_a(cw.fg * 8 + u + 1, (u + 1) & 1); issue_x(nfg, u); }
+            else issue_a(nfg * 8, 0);
+            const unsigned char* slot = aslots + (u & 1) * kUnitBytes + la;
+            floatx4 out[3] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+            // entries in d-major order (n -> d = n / 3, r = n % 3, entry 4 r + d); fragments of entry n + 1 requested before the
+            // MFMAs of entry n, entry n - 1 folded into the outputs while the matrix pipe works on entry n
+            half8 af[2][2];
+            floatx4 t[2];
+            af[0][0] = rd(slot); af[0][1] = rd(slot + 1024);
+#pragma unroll
+            for (int n = 0; n <= 12; ++n) {
+                if (n + 1 < 12) {
+                    const int e1 = 4 * ((n + 1) % 3) + (n + 1) / 3;
+                    af[(n + 1) & 1][0] = rd(slot + e1 * 2048); af[(n + 1) & 1][1] = rd(slot + e1 * 2048 + 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (n < 12) {
+                    floatx4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][0], wf[0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][1], wf[1], acc, 0, 0, 0);
+                    t[n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][0], wf[2], acc, 0, 0, 0);
+                }
+                if (n > 0) {
+                    const int d = (n - 1) / 3, r = (n - 1) % 3;
+                    if (d < 3) out[r] += t[(n - 1) & 1] * vp[u][d]; else out[r] += t[(n - 1) & 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // one 12-byte store per (frame, vertex): lane (vertex row, g) holds frames 4 g .. 4 g + 3 of the unit
+            const int fbase = (cw.fg * 8 + u) * 16 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = fbase + i;
+                const bool ok = okv && f < a.num_frames;
+                float3v x;
+                x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
+                float* dst = ok ? orow + (size_t)f * a.out_stride * 3 : dump;
+                *reinterpret_cast<float3v*>(dst) = x;
+            }
+            if (has_joint) {                           // rare (21 of 6890 vertices): the vertex again, into the joints array
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = fbase + i;
+                    if (jrow != 0 && okv && f < a.num_frames) {
+                        float3v x;
+                        x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
+                        *reinterpret_cast<float3v*>(a.joints_out + ((size_t)f * a.joints_stride + a.joints_row0 + jrow - 1) * 3) = x;
+                    }
+                }
+            }
+        }
+        // buffers 1 and 2 hold the next tile's k-steps 0 and 1 (landed long ago: the waits of the units covered them); the empty
+        // statement pins the copies behind this point - the compiler takes an asm load's result for ready at once
+        asm volatile("" : "+v"(pb1[0][0]), "+v"(pb1[0][1]), "+v"(pb1[1][0]), "+v"(pb1[1][1]), "+v"(pb1[2][0]), "+v"(pb1[2][1]),
+                          "+v"(pb2[0][0]), "+v"(pb2[0][1]), "+v"(pb2[1][0]), "+v"(pb2[1][1]), "+v"(pb2[2][0]), "+v"(pb2[2][1]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { pb0[c][h] = pb1[c][h]; pb1[c][h] = pb2[c][h]; }
+        cw = nw;
+    }
+    wait_vmcnt<0>();
+}
+
+hipError_t launch_skin_stream(const StreamArgs& a_in, int num_cus, hipStream_t stream) {
+    if (a_in.num_frames <= 0 || a_in.num_out <= 0) return hipSuccess;
+    StreamArgs a = a_in;
+    if ((a.nv16 & 7) || a.f32_tiles <= 0) return hipErrorInvalidValue;
+    const long long tiles = (long long)(a.nv16 >> 3) * ((a.f32_tiles + 3) >> 2);
+    int wgs = num_cus < 8 ? 8 : num_cus / 8 * 8;           // one persistent workgroup per CU, a multiple of the 8 XCD labels
+    if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
+    a.num_wgs = wgs;
+    const size_t lds = (size_t)kXBytes + 2 * kUnitBytes;
+    static std::atomic<unsigned long long> lds_set{0};
+    const hipError_t e = ensure_dynamic_lds(k2b_lbs_stream_kernel, lds_set, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k2b_lbs_stream_kernel, dim3(wgs), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace k2b
