@@ -34,6 +34,18 @@ struct __attribute__((packed, aligned(4))) float3v { float x, y, z; };
 constexpr int SKX = kStreamKSteps;                 // 32-deep k-steps of the pose GEMM
 constexpr int kXBytes = SKX * 16 * 1024;
 constexpr int kUnitBytes = 24 * 1024;              // A operand of one 16-frame unit: 12 entries x 2 fragments
+// diagnostics live in tools/lbs_diag.h (tools/build_lbs_variants.sh); the product build leaves the hooks empty
+#ifdef K2B_LBS_DIAG_HEADER
+#include K2B_LBS_DIAG_HEADER
+#endif
+#ifndef K2B_SDIAG_BEGIN
+#define K2B_SDIAG_BEGIN ((void)0)
+#define K2B_SDIAG_END ((void)0)
+#endif
+#ifndef K2B_SDIAG_STAMP
+#define K2B_SDIAG_STAMP(i) ((void)0)
+#define K2B_SDIAG_TILE ((void)0)
+#endif
 constexpr int CHUNK = 8;                           // frame groups per L2 chunk of the tile walk (as the tile kernel)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -83,6 +95,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
     Walk cw;
     cw.init(nv16 >> 3, (f32tiles + 3) >> 2, blockIdx.x, a.num_wgs);
     if (!cw.valid) return;
+    K2B_SDIAG_BEGIN;
 
     // ---- issue helpers (all addresses wave-uniform + lane x 16 B) ----------------------------------------------------------
     // X of k-step ks: 16 pieces [k-half 2][32-frame tile 4][hi | lo]; wave w moves (k-half w >> 2, frame tile w & 3), hi and lo
@@ -136,6 +149,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
         nw.next();
         const int nfg = nw.valid ? nw.fg : cw.fg, nvg = nw.valid ? nw.vg : cw.vg;   // (no next tile: the same addresses again,
                                                                                      //  so that the counted waits keep their counts)
+        K2B_SDIAG_STAMP(0);
         floatx4 vp[8][3];         // [16-frame tile][coordinate]
 #pragma unroll
         for (int f = 0; f < 8; ++f)
@@ -157,33 +171,43 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
             }
         };
         // younger than the awaited loads at each wait (in issue order): see the table in DESIGN.md 4.2
-        if (first) K2B_PD_READY(6, pb0);               // k-step 0: behind the prologue only k-step 1 is younger,
-        else K2B_PD_READY(7, pb0);                     // later the A fills + stores of the previous tile's last unit
-        first = false;
+        // k-step 0 was loaded during the previous tile's pose phase: more than 63 operations of the transform phase are younger, so
+        // "at most 63 outstanding" (the counter's ceiling) already means it has landed - and does NOT wait for the transform
+        // phase's last stores, whose acknowledgements take thousands of cycles when every CU writes at once (stores and loads share
+        // the counter and retire in order).  Behind the prologue only k-step 1 (6 loads) is younger.
+        if (first) K2B_PD_READY(6, pb0); else K2B_PD_READY(63, pb0);
         {                                              // W fragments of this tile's vertices, Pd two k-steps ahead
             const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w + ((size_t)cw.vg * 8 + wave) * 3 * 512);
             gload16<0>(wf[0], lane16, wbase); gload16<1024>(wf[1], lane16, wbase); gload16<2048>(wf[2], lane16, wbase);
         }
         load_pd(pb2, cw.vg, 2);
         kstep(0, pb0);
-        K2B_PD_READY(9, pb1);                          // k-step 1: W (3) and k-step 2 (6) are younger
+        K2B_SDIAG_STAMP(1);
+        if (first) K2B_PD_READY(9, pb1); else K2B_PD_READY(63, pb1);   // k-step 1: W (3) and k-step 2 (6) are younger (+ the transform phase)
+        first = false;
         load_pd(pb0, cw.vg, 3);
         kstep(1, pb1);
+        K2B_SDIAG_STAMP(2);
         K2B_PD_READY(6, pb2);
         load_pd(pb1, cw.vg, 4);
         kstep(2, pb2);
+        K2B_SDIAG_STAMP(3);
         K2B_PD_READY(6, pb0);
         load_pd(pb2, cw.vg, 5);
         kstep(3, pb0);
+        K2B_SDIAG_STAMP(4);
         K2B_PD_READY(6, pb1);
         load_pd(pb0, cw.vg, 6);
         kstep(4, pb1);
+        K2B_SDIAG_STAMP(5);
         K2B_PD_READY(6, pb2);
         load_pd(pb1, nvg, 0);                          // the next tile's first two k-steps ride through the transform phase
         kstep(5, pb2);
+        K2B_SDIAG_STAMP(6);
         K2B_PD_READY(6, pb0);
         load_pd(pb2, nvg, 1);
         kstep(6, pb0);
+        K2B_SDIAG_STAMP(7);
 #pragma unroll
         for (int f = 0; f < 8; ++f)
 #pragma unroll
@@ -201,9 +225,11 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
             // A of this unit has landed (each wave waits for its own pieces, the barrier collects them); what may stay in flight is
             // younger: the previous unit's 2 X fills + 4 stores (unit 0: the 12 Pd loads for the next tile; unit 7: stores only,
             // because the last X fills must be visible to every wave before the next pose phase)
+            K2B_SDIAG_STAMP(8 + 3 * u);
             if (u == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2])::"memory");   // (W: loaded at k-step 0)
             else if (u == 7) wait_vmcnt<4>(); else wait_vmcnt<6>();
             wg_barrier();
+            K2B_SDIAG_STAMP(9 + 3 * u);
             if (u == 0 && a.joints_out) {              // (W fragments are long there: they are older than everything waited for)
                 const float tg = (float)wf[1][0];      // lanes g == 3 hold the padding group of their row
                 jrow = (int)__shfl(tg, 48 + row, 64);
@@ -237,6 +263,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            K2B_SDIAG_STAMP(10 + 3 * u);
             // one 12-byte store per (frame, vertex): lane (vertex row, g) holds frames 4 g .. 4 g + 3 of the unit
             const int fbase = (cw.fg * 8 + u) * 16 + 4 * g;
 #pragma unroll
@@ -269,8 +296,10 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
 #pragma unroll
             for (int h = 0; h < 2; ++h) { pb0[c][h] = pb1[c][h]; pb1[c][h] = pb2[c][h]; }
         cw = nw;
+        K2B_SDIAG_TILE;
     }
     wait_vmcnt<0>();
+    K2B_SDIAG_END;
 }
 
 hipError_t launch_skin_stream(const StreamArgs& a_in, int num_cus, hipStream_t stream) {

@@ -12,7 +12,8 @@ for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   # (-DK2B_LBS_STREAM=0 is a switch of k2b_api.hip: that object is rebuilt with the same definitions)
   /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_api.hip -o /tmp/k2b_api_$name.o
+  /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_lbs_stream.hip -o /tmp/k2b_lbs_stream_$name.o
   /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_lbs.hip -o /tmp/k2b_lbs_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libk2b_$name.so /tmp/k2b_api_$name.o k2b_fit.o k2b_fit_tree.o /tmp/k2b_lbs_$name.o k2b_lbs_stream.o k2b_precompute.o k2b_metrics.o k2b_vertex.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libk2b_$name.so /tmp/k2b_api_$name.o k2b_fit.o k2b_fit_tree.o /tmp/k2b_lbs_$name.o /tmp/k2b_lbs_stream_$name.o k2b_precompute.o k2b_metrics.o k2b_vertex.o
   echo "built tools/libk2b_$name.so ($defs)"
 done

@@ -54,3 +54,31 @@
 #define K2B_DIAG_TILE_DONE ((void)0)
 #define K2B_DIAG_KERNEL_END ((void)0)
 #endif
+
+// ---- stream kernel (k2b_lbs_stream.hip) -------------------------------------------------------------------------------------
+//   K2B_STREAM_DIAG 1: in-kernel clock.  Lane 0 of wave 0 of every workgroup stamps s_memtime (shader cycles) and s_memrealtime
+//   (100 MHz) at the start and the end of its tile loop into the model's scratch row: [1024 + 4 block .. + 3] dwords = d cycles,
+//   d realtime ticks, tiles, 0 (tools/dev_lbs_clock.py: clock = d cycles / d ticks x 100 MHz, median over workgroups).
+//   K2B_STREAM_DIAG 2: s_memtime stamps of the workgroup's THIRD tile, every wave, 32 points (0 tile start, 1-7 after each pose
+//   k-step, then per unit u: 8 + 3u before the counted wait, 9 + 3u behind the barrier, 10 + 3u MFMAs issued, before the
+//   stores): blocks 0 and 77 write [1024 + 2048 b' + (wave 32 + i)] dwords (tools/dev_lbs_sstamps.py).
+#if K2B_STREAM_DIAG == 2
+#define K2B_SDIAG_BEGIN int sd_tile = 0
+#define K2B_SDIAG_STAMP(i)                                                                     \
+    do { if (sd_tile == 2 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 77))                \
+             reinterpret_cast<unsigned*>(a.dump)[1024 + (blockIdx.x ? 2048 : 0) + wave * 32 + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define K2B_SDIAG_TILE ++sd_tile
+#define K2B_SDIAG_END ((void)0)
+#endif
+#if K2B_STREAM_DIAG == 1
+#define K2B_SDIAG_BEGIN                                                                        \
+    const unsigned long long sd_t0 = __builtin_amdgcn_s_memtime(), sd_r0 = __builtin_amdgcn_s_memrealtime()
+#define K2B_SDIAG_END                                                                          \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 256) {                                            \
+            unsigned* d = reinterpret_cast<unsigned*>(a.dump) + 1024 + 4 * blockIdx.x;         \
+            d[0] = (unsigned)(__builtin_amdgcn_s_memtime() - sd_t0);                           \
+            d[1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - sd_r0);                       \
+        }                                                                                      \
+    } while (0)
+#endif
