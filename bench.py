@@ -44,7 +44,7 @@ FIT_FLOP_PER_FRAME_ITER = {"smpl": 0.11e6, "smplx": 0.106e6}
 FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 HBM_PEAK_GBS = 8000.0
 ROUND = "r03"
-LBS_KERNELS = "k2b_pose_setup_kernel+k2b_lbs_tile_kernel+k2b_gather_joints_kernel"
+LBS_KERNELS = {"smpl": "k2b_pose_setup_kernel+k2b_lbs_stream_kernel", "smplx": "k2b_pose_setup_kernel+k2b_lbs_tile_kernel"}
 PREWARM_S = 0.3        # seconds of untimed load before the warm-up steps (device clock ramp, see measure())
 
 
@@ -447,7 +447,7 @@ def main():
                 "note": f"algorithmic fp32 flops ({flop_iter / 1e6:.3f} MFLOP per frame-iteration) against the fp32 vector peak",
             },
             "roofline_lbs": {
-                "kernel": LBS_KERNELS, "bound": "hbm",
+                "kernel": LBS_KERNELS[args.model], "bound": "hbm",
                 "achieved": round(lbs_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(lbs_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_lbs, "avg_launch_ms": round(r["lbs_ms"], 4),
                 "bytes_per_frame": lbs_bytes,

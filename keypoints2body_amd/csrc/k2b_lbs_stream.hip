@@ -21,6 +21,8 @@
 // shape coefficients); everything else runs the tile kernel.
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "k2b_internal.h"
 
 namespace k2b {
@@ -58,25 +60,31 @@ __device__ __forceinline__ void gload16(half8& dst, unsigned lane_off, const voi
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(sbase), "n"(OFF) : "memory");
 }
 
+// 16-byte LDS read whose completion the code waits for itself (counted lgkmcnt waits that name the registers): the
+// compiler's own waits are lgkmcnt(0) in front of the first use, which stalls a wave on every fragment it has just requested
+template <int OFF>
+__device__ __forceinline__ void lread16(half8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+#define K2B_LDS_READY2(N, b) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory")
+
 struct Walk {                  // (frame group, vertex group) tiles of this workgroup, XCD-aware: see TileWalk in k2b_lbs.hip
-    int vgroups, fgroups, item_lo, item_hi, nx, t, fg, vg;
-    bool valid;
+    int vgroups, fgroups, item_lo, item_hi, nx;
     __device__ void init(int vgroups_, int fgroups_, int block, int nblocks) {
         vgroups = vgroups_; fgroups = fgroups_;
         const int items = ((fgroups + CHUNK - 1) / CHUNK) * vgroups, x = block & 7;
         item_lo = (int)((long long)items * x / 8); item_hi = (int)((long long)items * (x + 1) / 8);
         nx = nblocks >> 3;
-        t = (block >> 3) - nx;
-        next();
     }
-    __device__ void next() {
+    // the tile behind sequence index t (advanced to the next valid one), or fg = -1 when the workgroup's sequence is exhausted
+    __device__ void next(int& t, int& fg, int& vg) const {
         for (;;) {
             t += nx;
             const int item = item_lo + t / CHUNK;
-            if (item >= item_hi) { valid = false; return; }
+            if (item >= item_hi) { fg = -1; vg = 0; return; }
             const int c = item / vgroups;
             fg = c * CHUNK + t % CHUNK; vg = item - c * vgroups;
-            if (fg < fgroups) { valid = true; return; }
+            if (fg < fgroups) return;
         }
     }
 };
@@ -92,9 +100,11 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
     const int f32tiles = a.f32_tiles, f16tiles = 2 * f32tiles, nv16 = a.nv16;
     const unsigned lane16 = (unsigned)lane * 16u;
 
-    Walk cw;
-    cw.init(nv16 >> 3, (f32tiles + 3) >> 2, blockIdx.x, a.num_wgs);
-    if (!cw.valid) return;
+    Walk walk;
+    walk.init(nv16 >> 3, (f32tiles + 3) >> 2, blockIdx.x, a.num_wgs);
+    int wt = (blockIdx.x >> 3) - walk.nx, cfg, cvg;          // sequence index, frame group and vertex group of the current tile
+    walk.next(wt, cfg, cvg);
+    if (cfg < 0) return;
     K2B_SDIAG_BEGIN;
 
     // ---- issue helpers (all addresses wave-uniform + lane x 16 B) ----------------------------------------------------------
@@ -127,106 +137,123 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
     asm volatile("s_waitcnt vmcnt(%6)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]) : "n"(N) : "memory")
 
     const int lx = (g >> 1) * 8192 + (g & 1) * 512 + row * 16;      // lane part of an X fragment address inside a k-step
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;                  // LDS byte address of the X region
+    const unsigned lxa = lds0 + lx, lxb = lxa + 65536;               // (the 16-bit offset field reaches four k-steps)
     const int la = g * 256 + row * 16;                               // lane part of an A fragment address inside a piece
     const float inv_scale = 1.0f / kPdScale;
-    float* const dump = a.dump + lane * 3;
-    auto rd = [&](const unsigned char* p) -> half8 { return *reinterpret_cast<const half8*>(p); };
 
     // ---- prologue: everything the first tile needs ------------------------------------------------------------------------
     half8 pb0[3][2], pb1[3][2], pb2[3][2];      // Pd buffers: k-step ks lives in buffer ks % 3
     half8 wf[3];                                // W fragments of this wave's 16 vertices: [hi | 1], [hi | tag], [lo | 0]
 #pragma unroll
-    for (int ks = 0; ks < SKX; ++ks) issue_x(cw.fg, ks);            // 14 fills
-    issue_a(cw.fg * 8, 0);                                          // 3 fills
-    load_pd(pb0, cw.vg, 0);                                         // 6 loads
-    load_pd(pb1, cw.vg, 1);                                         // 6 loads
-    wait_vmcnt<12>();                                               // X and the first A unit of this wave have landed
+    for (int ks = 0; ks < SKX; ++ks) issue_x(cfg, ks);            // 14 fills
+    issue_a(cfg * 8, 0);                                          // 3 fills
+    load_pd(pb0, cvg, 0);                                         // 6 loads
+    load_pd(pb1, cvg, 1);                                         // 6 loads
+    K2B_PD_READY(0, pb0);                                           // everything of the prologue has landed (once per launch)
+    K2B_PD_READY(0, pb1);
     wg_barrier();
 
-    bool first = true;
-    while (cw.valid) {
-        Walk nw = cw;
-        nw.next();
-        const int nfg = nw.valid ? nw.fg : cw.fg, nvg = nw.valid ? nw.vg : cw.vg;   // (no next tile: the same addresses again,
-                                                                                     //  so that the counted waits keep their counts)
+    while (cfg >= 0) {
+        int nt = wt, nxf, nxv;
+        walk.next(nt, nxf, nxv);
+        const int nfg = nxf >= 0 ? nxf : cfg, nvg = nxf >= 0 ? nxv : cvg;   // (no next tile: the same addresses again, so that the
+                                                                             //  counted waits keep their counts)
         K2B_SDIAG_STAMP(0);
-        floatx4 vp[8][3];         // [16-frame tile][coordinate]
-#pragma unroll
-        for (int f = 0; f < 8; ++f)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) vp[f][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+        floatx4 vp[8][3];         // [16-frame tile][coordinate]; the first k-step starts every accumulator from zero
 
         // ---- pose phase: v_posed * kPdScale = X . Pd, no barrier -------------------------------------------------------------
-        auto kstep = [&](int ks, const half8 (&pd)[3][2]) {
-            const unsigned char* xb = lds + ks * 16384 + lx;
-#pragma unroll
-            for (int f = 0; f < 8; ++f) {
-                const half8 xh = rd(xb + (f >> 1) * 2048 + (f & 1) * 256), xl = rd(xb + (f >> 1) * 2048 + 1024 + (f & 1) * 256);
+        // X fragments (hi | lo of one 16-frame tile), two buffers: tile q + 1 of the phase's 56 is requested before the nine MFMAs of
+        // tile q, and a counted wait leaves those two reads in flight
+        half8 xq[2][2];
+        auto xread = [&](half8 (&dst)[2], auto ksc, auto fc) {
+            constexpr int ks = decltype(ksc)::value, f = decltype(fc)::value;
+            constexpr int off = (ks & 3) * 16384 + (f >> 1) * 2048 + (f & 1) * 256;
+            const unsigned base = ks < 4 ? lxa : lxb;
+            lread16<off>(dst[0], base); lread16<off + 1024>(dst[1], base);
+        };
+        auto kstep = [&](auto ksc, const half8 (&pd)[3][2]) {
+            constexpr int ks = decltype(ksc)::value;
+            auto tile = [&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                half8 (&cur)[2] = xq[f & 1];
+                if constexpr (f < 7) xread(xq[(f + 1) & 1], ksc, std::integral_constant<int, (f + 1) & 7>{});
+                else if constexpr (ks < SKX - 1) xread(xq[0], std::integral_constant<int, (ks + 1) % SKX>{}, std::integral_constant<int, 0>{});
+                if constexpr (f < 7 || ks < SKX - 1) K2B_LDS_READY2(2, cur); else K2B_LDS_READY2(0, cur);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, pd[c][0], vp[f][c], 0, 0, 0);
-                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, pd[c][1], vp[f][c], 0, 0, 0);
-                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, pd[c][0], vp[f][c], 0, 0, 0);
+                    if constexpr (ks == 0) vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[0], pd[c][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[0], pd[c][0], vp[f][c], 0, 0, 0);
+                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[0], pd[c][1], vp[f][c], 0, 0, 0);
+                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[1], pd[c][0], vp[f][c], 0, 0, 0);
                 }
-            }
+            };
+            tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{});
+            tile(std::integral_constant<int, 3>{}); tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
+            tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
         };
+        xread(xq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         // younger than the awaited loads at each wait (in issue order): see the table in DESIGN.md 4.2
         // k-step 0 was loaded during the previous tile's pose phase: more than 63 operations of the transform phase are younger, so
         // "at most 63 outstanding" (the counter's ceiling) already means it has landed - and does NOT wait for the transform
         // phase's last stores, whose acknowledgements take thousands of cycles when every CU writes at once (stores and loads share
-        // the counter and retire in order).  Behind the prologue only k-step 1 (6 loads) is younger.
-        if (first) K2B_PD_READY(6, pb0); else K2B_PD_READY(63, pb0);
-        {                                              // W fragments of this tile's vertices, Pd two k-steps ahead
-            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w + ((size_t)cw.vg * 8 + wave) * 3 * 512);
-            gload16<0>(wf[0], lane16, wbase); gload16<1024>(wf[1], lane16, wbase); gload16<2048>(wf[2], lane16, wbase);
-        }
-        load_pd(pb2, cw.vg, 2);
-        kstep(0, pb0);
+        // the counter and retire in order).  (First tile: the prologue waited for everything.)
+        K2B_PD_READY(63, pb0);
+        load_pd(pb2, cvg, 2);                        // Pd two k-steps ahead
+        kstep(std::integral_constant<int, 0>{}, pb0);
         K2B_SDIAG_STAMP(1);
-        if (first) K2B_PD_READY(9, pb1); else K2B_PD_READY(63, pb1);   // k-step 1: W (3) and k-step 2 (6) are younger (+ the transform phase)
-        first = false;
-        load_pd(pb0, cw.vg, 3);
-        kstep(1, pb1);
+        K2B_PD_READY(63, pb1);                         // (likewise)
+        load_pd(pb0, cvg, 3);
+        kstep(std::integral_constant<int, 1>{}, pb1);
         K2B_SDIAG_STAMP(2);
         K2B_PD_READY(6, pb2);
-        load_pd(pb1, cw.vg, 4);
-        kstep(2, pb2);
+        load_pd(pb1, cvg, 4);
+        kstep(std::integral_constant<int, 2>{}, pb2);
         K2B_SDIAG_STAMP(3);
         K2B_PD_READY(6, pb0);
-        load_pd(pb2, cw.vg, 5);
-        kstep(3, pb0);
+        load_pd(pb2, cvg, 5);
+        kstep(std::integral_constant<int, 3>{}, pb0);
         K2B_SDIAG_STAMP(4);
         K2B_PD_READY(6, pb1);
-        load_pd(pb0, cw.vg, 6);
-        kstep(4, pb1);
+        load_pd(pb0, cvg, 6);
+        kstep(std::integral_constant<int, 4>{}, pb1);
         K2B_SDIAG_STAMP(5);
         K2B_PD_READY(6, pb2);
         load_pd(pb1, nvg, 0);                          // the next tile's first two k-steps ride through the transform phase
-        kstep(5, pb2);
+        kstep(std::integral_constant<int, 5>{}, pb2);
         K2B_SDIAG_STAMP(6);
         K2B_PD_READY(6, pb0);
+        {                                              // W fragments of this tile's vertices (needed behind the pose phase: 12 registers less until here)
+            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w + ((size_t)cvg * 8 + wave) * 3 * 512);
+            gload16<0>(wf[0], lane16, wbase); gload16<1024>(wf[1], lane16, wbase); gload16<2048>(wf[2], lane16, wbase);
+        }
         load_pd(pb2, nvg, 1);
-        kstep(6, pb0);
+        kstep(std::integral_constant<int, 6>{}, pb0);
         K2B_SDIAG_STAMP(7);
 #pragma unroll
         for (int f = 0; f < 8; ++f)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) vp[f][c] *= inv_scale;
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { vp[f][c][i] *= inv_scale; asm volatile("" : "+v"(vp[f][c][i])); }
 
         // ---- transform phase: one 16-frame unit at a time ---------------------------------------------------------------------
         // this wave's vertex, and the output joint it may be (tag = 1 + index, first half of the padding group of fragment 1)
-        const int v = (cw.vg * 8 + wave) * 16 + row;
+        const int v = (cvg * 8 + wave) * 16 + row;
         const bool okv = v < a.num_out;
         int jrow = 0;
         bool has_joint = false;
-        float* const orow = a.out + ((size_t)a.out_row0 + v) * 3;
+        const size_t row_bytes = (size_t)a.out_stride * 12;                     // one frame of the output
+        // this lane's (vertex, first frame 4 g of unit 0) in the output; rows of the unit's other frames are uniform offsets from it
+        unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + ((size_t)a.out_row0 + v) * 12 + (size_t)(cfg * 128 + 4 * g) * row_bytes;
+        const bool tile_full = cfg * 128 + 127 < a.num_frames && (cvg * 8 + wave) * 16 + 15 < a.num_out;   // wave-uniform
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             // A of this unit has landed (each wave waits for its own pieces, the barrier collects them); what may stay in flight is
-            // younger: the previous unit's 2 X fills + 4 stores (unit 0: the 12 Pd loads for the next tile; unit 7: stores only,
+            // younger: the previous unit's 2 X fills + 4 stores (unit 0: the 6 Pd loads of the next tile's k-step 1; unit 7: stores only,
             // because the last X fills must be visible to every wave before the next pose phase)
             K2B_SDIAG_STAMP(8 + 3 * u);
-            if (u == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2])::"memory");   // (W: loaded at k-step 0)
+            if (u == 0) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2])::"memory");   // (W: loaded at k-step 6, in front of the next tile's k-step 1)
             else if (u == 7) wait_vmcnt<4>(); else wait_vmcnt<6>();
             wg_barrier();
             K2B_SDIAG_STAMP(9 + 3 * u);
@@ -236,44 +263,64 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
                 has_joint = __builtin_amdgcn_ballot_w64(jrow != 0) != 0;
             }
             // behind the barrier the other slot and (after unit 0) the X region are free: next unit's A, next tile's X k-step u
-            if (u < 7) { issue_a(cw.fg * 8 + u + 1, (u + 1) & 1); issue_x(nfg, u); }
+            if (u < 7) { issue_a(cfg * 8 + u + 1, (u + 1) & 1); issue_x(nfg, u); }
             else issue_a(nfg * 8, 0);
-            const unsigned char* slot = aslots + (u & 1) * kUnitBytes + la;
             floatx4 out[3] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
             // entries in d-major order (n -> d = n / 3, r = n % 3, entry 4 r + d); fragments of entry n + 1 requested before the
             // MFMAs of entry n, entry n - 1 folded into the outputs while the matrix pipe works on entry n
             half8 af[2][2];
             floatx4 t[2];
-            af[0][0] = rd(slot); af[0][1] = rd(slot + 1024);
-#pragma unroll
-            for (int n = 0; n <= 12; ++n) {
-                if (n + 1 < 12) {
-                    const int e1 = 4 * ((n + 1) % 3) + (n + 1) / 3;
-                    af[(n + 1) & 1][0] = rd(slot + e1 * 2048); af[(n + 1) & 1][1] = rd(slot + e1 * 2048 + 1024);
+            const unsigned sa = lds0 + kXBytes + (u & 1) * kUnitBytes + la;
+            lread16<0>(af[0][0], sa); lread16<1024>(af[0][1], sa);
+            auto entry = [&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n + 1 < 12) {
+                    constexpr int e1 = 4 * ((n + 1) % 3) + (n + 1) / 3;
+                    lread16<e1 * 2048>(af[(n + 1) & 1][0], sa); lread16<e1 * 2048 + 1024>(af[(n + 1) & 1][1], sa);
                 }
+                if constexpr (n + 1 < 12) K2B_LDS_READY2(2, af[n & 1]); else if constexpr (n < 12) K2B_LDS_READY2(0, af[n & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (n < 12) {
+                if constexpr (n < 12) {
                     floatx4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][0], wf[0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][1], wf[1], acc, 0, 0, 0);
                     t[n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][0], wf[2], acc, 0, 0, 0);
                 }
-                if (n > 0) {
-                    const int d = (n - 1) / 3, r = (n - 1) % 3;
-                    if (d < 3) out[r] += t[(n - 1) & 1] * vp[u][d]; else out[r] += t[(n - 1) & 1];
+                if constexpr (n > 0) {
+                    constexpr int d = (n - 1) / 3, r = (n - 1) % 3;
+                    // element by element: written on the 4-vectors this becomes v_pk_fma_f32 / v_pk_add_f32, which issue at well under
+                    // half the rate of the scalar forms beside MFMAs (MI355X_MICROARCH.md) - and the transform phase is VALU-issue-bound
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (d < 3) out[r][i] = __builtin_fmaf(t[(n - 1) & 1][i], vp[u][d][i], out[r][i]);
+                        else out[r][i] += t[(n - 1) & 1][i];
+                        asm volatile("" : "+v"(out[r][i]));   // fold NOW (left to itself the compiler keeps all twelve T tiles, 48 registers, for
+                    }                                         // the end) and do not re-pack
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            entry(std::integral_constant<int, 0>{}); entry(std::integral_constant<int, 1>{}); entry(std::integral_constant<int, 2>{});
+            entry(std::integral_constant<int, 3>{}); entry(std::integral_constant<int, 4>{}); entry(std::integral_constant<int, 5>{});
+            entry(std::integral_constant<int, 6>{}); entry(std::integral_constant<int, 7>{}); entry(std::integral_constant<int, 8>{});
+            entry(std::integral_constant<int, 9>{}); entry(std::integral_constant<int, 10>{}); entry(std::integral_constant<int, 11>{});
+            entry(std::integral_constant<int, 12>{});
             K2B_SDIAG_STAMP(10 + 3 * u);
             // one 12-byte store per (frame, vertex): lane (vertex row, g) holds frames 4 g .. 4 g + 3 of the unit
-            const int fbase = (cw.fg * 8 + u) * 16 + 4 * g;
+            const int fbase = (cfg * 8 + u) * 16 + 4 * g;
+            if (tile_full) {                           // every (frame, vertex) of the tile exists: lane base + a wave-uniform row offset
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = fbase + i;
-                const bool ok = okv && f < a.num_frames;
-                float3v x;
-                x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
-                float* dst = ok ? orow + (size_t)f * a.out_stride * 3 : dump;
-                *reinterpret_cast<float3v*>(dst) = x;
+                for (int i = 0; i < 4; ++i) {
+                    float3v x;
+                    x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
+                    *reinterpret_cast<float3v*>(obase + (size_t)(u * 16 + i) * row_bytes) = x;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = fbase + i;
+                    float3v x;
+                    x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
+                    if (okv && f < a.num_frames) *reinterpret_cast<float3v*>(obase + (size_t)(u * 16 + i) * row_bytes) = x;
+                }
             }
             if (has_joint) {                           // rare (21 of 6890 vertices): the vertex again, into the joints array
 #pragma unroll
@@ -295,7 +342,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int h = 0; h < 2; ++h) { pb0[c][h] = pb1[c][h]; pb1[c][h] = pb2[c][h]; }
-        cw = nw;
+        wt = nt; cfg = nxf; cvg = nxv;
         K2B_SDIAG_TILE;
     }
     wait_vmcnt<0>();

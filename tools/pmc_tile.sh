@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the LBS tile kernel (run on the GPU box): tools/pmc_tile.sh TAG FRAMES [LIB]
+# PMC passes over the LBS vertex kernel (stream / tile) (run on the GPU box): tools/pmc_tile.sh TAG FRAMES [LIB]
 # Counters in separate passes (kernel-trace only beside --pmc), summary printed and written to gpurun_out/pmct_TAG.txt
 TAG=$1; FR=$2; LIB=${3:--}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmct_$TAG
@@ -18,11 +18,11 @@ acc = collections.defaultdict(list)
 dur = []
 for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if 'lbs_tile' in r['Kernel_Name'] and int(r['Grid_Size']) > 100000:
+        if ('lbs_tile' in r['Kernel_Name'] or 'lbs_stream' in r['Kernel_Name']) and int(r['Grid_Size']) > 100000:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for f in glob.glob("$OUT/p*/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
-        if 'lbs_tile' in r['Kernel_Name'] and int(r['Grid_Size_X']) > 100000:
+        if ('lbs_tile' in r['Kernel_Name'] or 'lbs_stream' in r['Kernel_Name']) and int(r['Grid_Size_X']) > 100000:
             dur.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 print("frames $FR lib $LIB: tile kernel launches", len(dur), "avg", sum(dur) / max(1, len(dur)) / 1e3, "us")
 for k in sorted(acc): print(f"{k:32s} {sum(acc[k])/len(acc[k]):16.0f}  (n={len(acc[k])})")

@@ -1,8 +1,8 @@
 """Copy the measurement bundle of tools/profile_round.sh from gpurun_out/prof_<TAG>/ into profiles/ (files the judge
-reads) and write profiles/traffic_<ROUND>.json.  usage: python tools/save_profiles.py TAG [ROUND=r02]"""
+reads) and write profiles/traffic_<ROUND>.json.  usage: python tools/save_profiles.py TAG [ROUND=r03]"""
 import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 O = f'gpurun_out/prof_{tag}'
 P = f'profiles/{rnd}_final_'
 for f in glob.glob(P + '*'): os.remove(f)
@@ -13,7 +13,7 @@ for n in ('bench_default', 'bench_1024', 'bench_smplx_1024', 'bench_smplx_4096',
     shutil.copy(f'{O}/{n}.json', f'{P}{n}.json')
 t = {"_doc": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of the bench command); "
              "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for wide coalesced reads). KiB -> bytes. "
-             "lbs = pose set-up + tile kernel (full-mesh launch) + joint gather."}
+             "lbs = pose set-up + vertex kernel (stream kernel for SMPL, tile kernel for SMPL-X; the joint gather is part of it since round 3); lbs_tile_only = the vertex kernel alone."}
 for key, pre in (('4096', ''), ('1024', ''), ('x1024', 'smplx_')):
     out, vals = [], {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -23,7 +23,7 @@ for key, pre in (('4096', ''), ('1024', ''), ('x1024', 'smplx_')):
                     continue
                 kn = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
                 out.append((kn, r['Grid_Size'], r['Counter_Name'], r['Counter_Value']))
-                kind = 'fit' if 'fit_' in kn else ('tile' if 'lbs_tile' in kn else ('pose' if 'pose_setup' in kn else ('gather' if 'gather' in kn else None)))
+                kind = 'fit' if 'fit_' in kn else ('tile' if ('lbs_tile' in kn or 'lbs_stream' in kn) else ('pose' if 'pose_setup' in kn else ('gather' if 'gather' in kn else None)))
                 if kind:
                     vals.setdefault((kind, r['Counter_Name']), []).append((int(r['Grid_Size']), float(r['Counter_Value'])))
     if not vals:
