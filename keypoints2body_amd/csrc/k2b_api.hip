@@ -510,7 +510,7 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
     for (int m = 0; m < MG; ++m) p->inv_scale[m] = 1.0f;
     for (int m = 0; m < M; ++m) {
         double maxabs = 0.0;
-        for (int row = 0; row < NC; ++row)
+        for (int row = 0; row < D; ++row)          // core rows and the rim rows 64..68 (their fragments share the scale)
             for (int col = 0; col < NC; ++col) maxabs = std::max(maxabs, std::fabs(Ps[((size_t)m * D + row) * D + col]));
         int e = 0;
         if (maxabs > 0.0 && std::isfinite(maxabs)) e = 13 - (int)std::ceil(std::log2(maxabs));
@@ -528,6 +528,19 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
                         f32[((((size_t)m * 4 + t) * 4 + 2 + ks) * 64 + l) * 8 + j] = (k2b::k2b_half)(x - (float)hi);
                     }
             }
+        // rim rows 64..68 over the core columns as a FIFTH row tile (rows 69..79 are zero), kept compact in the LDS image:
+        // fragment f = 2 ks + (hi | lo), entry kg * 5 + row = the eight halfs of MFMA lane (row, k-group kg); entry 20 = zeros,
+        // read by the lanes of the tile's empty rows (k2b_fit.hip, comp_issue)
+        k2b::k2b_half* rf = reinterpret_cast<k2b::k2b_half*>(pa.data() + 2 * NR * 64 * 4 + MG * 2 * NC) + (size_t)m * k2b::kPriorRimFragEntries * 8;
+        for (int ks = 0; ks < 2; ++ks)
+            for (int g = 0; g < 4; ++g)
+                for (int row = 0; row < NR; ++row)
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = (float)(Ps[((size_t)m * D + NC + row) * D + 32 * ks + 8 * g + j] * scale);
+                        const k2b::k2b_half hi = (k2b::k2b_half)x;
+                        rf[((size_t)(2 * ks) * 21 + g * 5 + row) * 8 + j] = hi;
+                        rf[((size_t)(2 * ks + 1) * 21 + g * 5 + row) * 8 + j] = (k2b::k2b_half)(x - (float)hi);
+                    }
     }
     // upload; on any failure the partially built handle is released before the error is returned
     auto upload_all = [&]() -> hipError_t {

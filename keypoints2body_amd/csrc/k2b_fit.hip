@@ -66,14 +66,16 @@ constexpr int NR = D - NC;              // 5 rim rows / columns
 // parameters (row role -> tree / component roles), gradients (tree -> row), theta[0..63] as f16 hi | lo.
 constexpr int RIM_FLOATS = 2 * NR * 64 * 4;
 constexpr int CMU_FLOATS = MG * 2 * NC;
-static_assert(RIM_FLOATS + CMU_FLOATS == kPriorImageFloats, "host image size");
+constexpr int RF_FLOATS = MG * kPriorRimFragEntries * 4;   // rim rows 64..68 as a fifth MFMA row tile, compact (k2b_api.hip)
+static_assert(RIM_FLOATS + CMU_FLOATS + RF_FLOATS == kPriorImageFloats, "host image size");
 constexpr int XS = 96;                  // strip: go@0, body@4, betas@76, transl@92, joint loss@95
 constexpr int XS_BODY = 4, XS_BETA = 76, XS_TRANSL = 92;
 constexpr int SLOT = 2 * XS + NC + 4;   // 260 floats: the +4 spreads the 16 frame columns of the MFMA-side reads over the banks
 constexpr int YX_STRIDE = MG * NC + 4;  // y exchange: [slot][m][64] (+4: b128 stores of the 16 frame columns hit distinct banks)
 constexpr int DD_STRIDE_MAX = 52;        // per-lane stride of the J_dirs table in LDS (see the kernel)
 constexpr int PLO_FLOATS = MG * 4 * 2 * 64 * 4;   // lo fragments of all components (paired shape): [m][tile][ks][64 lanes][8 halfs]
-constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX + PLO_FLOATS;
+constexpr int WX_FLOATS = MAXS * 64;                 // rim rows' products: [slot][lane 8 m + s] = (P_m[64 + s][0..63] theta)[s < 5], zeros for s >= 5
+constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + RF_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX + PLO_FLOATS + WX_FLOATS;
 static_assert(LDS_FLOATS * 4 <= 163840, "LDS budget");
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -86,6 +88,21 @@ __device__ __forceinline__ float group8_sum(float v) {
     v += lane_xor2(v);
     v += dpp<0x141>(v);   // row_half_mirror
     return v;
+}
+
+// minimum over the wave of a value that is uniform inside each group of eight lanes
+// (v_min_f32 in asm: fminf() costs a canonicalising v_max_f32 per operand on top; NaNs lose against numbers either way)
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float group8_wave_min(float v) {
+    float r;
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    { float a = r, b = r; swap16(a, b); r = vmin(a, b); }
+    { float a = r, b = r; swap32(a, b); r = vmin(a, b); }
+    return r;
 }
 
 // sum over the 32-lane half of the lane
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     {
         const float4* src = reinterpret_cast<const float4*>(a.pa_image);
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = tid; i < (RIM_FLOATS + CMU_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = tid; i < (RIM_FLOATS + CMU_FLOATS + RF_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
     }
 
     // frame slots and roles of this wave
@@ -193,9 +210,9 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         f[h] = f_raw < a.num_frames ? f_raw : a.num_frames - 1;
     }
 
-    const float4* rim4 = reinterpret_cast<const float4*>(lds);          // [10][64]
     const float* cmu = lds + RIM_FLOATS;                                // [m][mu | c][64]
-    float* slots = lds + RIM_FLOATS + CMU_FLOATS;
+    const half8* rimfrag = reinterpret_cast<const half8*>(lds + RIM_FLOATS + CMU_FLOATS);   // [m][fragment 4][21 entries]
+    float* slots = lds + RIM_FLOATS + CMU_FLOATS + RF_FLOATS;
     float* qx = slots + MAXS * SLOT;                           // [slot][m]   core part of d^T P_m d
     float* yx = qx + MAXS * MG;                                // [slot][m][64] (stride YX_STRIDE)  core part of y_m, rows 0..63
     // J_dirs differences of every tree lane, [lane][3][NBT] at a stride that spreads the lanes' b128 reads
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     static_assert(DD_STRIDE <= DD_STRIDE_MAX, "LDS budget of the J_dirs table");
     float* ddl = yx + MAXS * YX_STRIDE;
     half8* plo = reinterpret_cast<half8*>(ddl + 64 * DD_STRIDE_MAX);   // paired shape: lo fragments, [m][tile][ks][lane]
+    float* wx = reinterpret_cast<float*>(plo) + PLO_FLOATS;           // [slot][64]
     if (PAIR && !SPLIT) {
         for (int i = tid; i < 64 * DDN; i += blockDim.x) {
             const int l = i / DDN, r = i % DDN;
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const int cn = lane & 15, cg = lane >> 4;
     const int cslot = cn < F ? cn : F - 1;                     // columns beyond the workgroup's frames repeat the last slot
     const float* cxs = slots + cslot * SLOT;                   // slot this lane's MFMA column reads
+    const int ridx = cn < NR ? cg * NR + cn : 4 * NR;          // this lane's entry in a compact rim fragment (as an A operand lane: row cn, k-group cg)
     const _Float16* cth_hi = reinterpret_cast<const _Float16*>(cxs + 2 * XS);
     const _Float16* cth_lo = cth_hi + NC;
 
@@ -247,11 +266,6 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     const float cB = a.row_const[5 * 64 + lane];    // (P mu)[64 + gs]
     const float kB = a.row_const[6 * 64 + lane];    // (P_BA mu_A)[gs]
     const float muB = a.row_const[7 * 64 + lane];   // mu[64 + gs]
-    // one-hot of gs over the five rim rows: "element gs of five" as a sum of products - hipcc turns the
-    // equivalent chain of ?: into lane-divergent branches
-    float mk[NR];
-#pragma unroll
-    for (int c = 0; c < NR; ++c) mk[c] = gs == c ? 1.f : 0.f;
     // float4 index of P_m[64 + c][lane] (= P_m[lane][64 + c]) in the rim image, without the m and c terms
     const int rimcol = (((lane >> 2) & 1) * 64 + (lane >> 3)) * 4 + (lane & 3);
 
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     //  the vector work issued in between)
     // (paired shape: the lo fragments are read from LDS each iteration instead of occupying 32 registers
     //  next to two frames of optimiser state)
-    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&plr)[4][2], floatx4 (&yacc)[4], int lds_comp) __attribute__((always_inline)) {
+    auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&plr)[4][2], floatx4 (&yacc)[5], int lds_comp, int comp) __attribute__((always_inline)) {
         // lds_comp >= 0: the lo fragments of that component are read from LDS instead of registers
         half8 pl[4][2];
 #pragma unroll
@@ -412,45 +426,22 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bh1, acc, 0, 0, 0);
             yacc[t] = acc;
         }
+        {   // fifth row tile: the rim rows 64..68 over the core columns (rows 69..79 are zero) - on the vector ALU this was 40 FMAs
+            // and 15 DPP adds per frame; here it is six more MFMAs per component for all sixteen frame columns
+            const half8* rf = rimfrag + comp * kPriorRimFragEntries + ridx;
+            const half8 rh0 = rf[0], rl0 = rf[21], rh1 = rf[42], rl1 = rf[63];
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl0, bh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl1, bh1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bl0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bl1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bh1, acc, 0, 0, 0);
+            yacc[4] = acc;
+        }
         // keep the B fragments live past the last MFMA so that no MFMA destination is allocated on
         // top of its own B operand
         asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
-    };
-
-    // ---- rim rows 64..68 on the vector ALU (row role) --------------------------------------------
-    // lane (gm, gs): w_c = sum over its 8 columns of P_gm[64 + c][col] theta[col] (columns 0..63), summed
-    // over the 8 lanes of the group; lane gs < 5 then finishes row 64 + gs:
-    //   y_B = w + P_BB theta_B - c_B
-    //   rim share of d^T P d = theta_B (P_BA d_A) + d_B y_B,   P_BA d_A = w - P_BA mu_A
-    float yB[FW], qrim[FW];
-    auto rim = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int h = 0; h < FW; ++h) {
-            yB[h] = 0.f; qrim[h] = 0.f;
-            if (use_gmm) {
-                const float* xs = slots + (slot0 + h) * SLOT;
-                const float4 ta = *reinterpret_cast<const float4*>(xs + XS_BODY + 8 * gs);
-                const float4 tb = *reinterpret_cast<const float4*>(xs + XS_BODY + 8 * gs + 4);
-                const float4 t64 = *reinterpret_cast<const float4*>(xs + XS_BODY + NC);      // theta_B[0..3]
-                const float t68 = xs[XS_BODY + NC + 4];
-                float w[NR];
-#pragma unroll
-                for (int c = 0; c < NR; ++c) {
-                    const float4 pa = rim4[(2 * c) * 64 + lane], pb = rim4[(2 * c + 1) * 64 + lane];
-                    w[c] = pa.x * ta.x + pa.y * ta.y + pa.z * ta.z + pa.w * ta.w + pb.x * tb.x + pb.y * tb.y + pb.z * tb.z + pb.w * tb.w;
-                }
-#pragma unroll
-                for (int c = 0; c < NR; ++c) w[c] = group8_sum(w[c]);
-                const float wm = mk[0] * w[0] + mk[1] * w[1] + mk[2] * w[2] + mk[3] * w[3] + mk[4] * w[4];        // w[gs]
-                const float tB = mk[0] * t64.x + mk[1] * t64.y + mk[2] * t64.z + mk[3] * t64.w + mk[4] * t68;   // theta_B[gs]
-                const float vB = pbb[0] * t64.x + pbb[1] * t64.y + pbb[2] * t64.z + pbb[3] * t64.w + pbb[4] * t68;
-                const float y = wm + vB - cB;
-                const float term = tB * (wm - kB) + (tB - muB) * y;
-                yB[h] = gs < NR ? y : 0.f;
-                qrim[h] = group8_sum(gs < NR ? term : 0.f);      // every lane of group gm: rim share of component gm
-            }
-        }
-
     };
 
     auto tree_pass = [&](bool last) __attribute__((always_inline)) {
@@ -589,7 +580,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     };
 
     // ---- component role: y = D / scale - c, core part of the quadratic form per frame, publish both ----
-    auto comp_consume = [&](const floatx4 (&yacc)[4], int comp) __attribute__((always_inline)) {
+    auto comp_consume = [&](const floatx4 (&yacc)[5], int comp) __attribute__((always_inline)) {
         const float inv_scale = a.inv_scale[comp];
         const float* cmu_c = cmu + comp * 2 * NC + 4 * cg;     // + 16 t: mu of this lane's rows; + NC: c
         float qp = 0.f;
@@ -611,10 +602,20 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         qp = pair_sum32(qp);
         qp = pair_sum16(qp);                             // summed over the four row groups g: all four hold the total
         qx[cslot * MG + comp] = qp;
+        // rim rows: accumulator rows 64 + 4 g + i; g = 0 holds rows 64..67, g = 1 row 68 and three zero rows
+        if (cg < 2) {
+            float4 w;
+            w.x = yacc[4][0] * inv_scale; w.y = yacc[4][1] * inv_scale; w.z = yacc[4][2] * inv_scale; w.w = yacc[4][3] * inv_scale;
+            *reinterpret_cast<float4*>(wx + cslot * 64 + comp * 8 + 4 * cg) = w;
+        }
     };
 
     // ---- row role, part 1 (needs y and q of every component, not the tree): arg-min component, its y in
     // row layout, and every prior's share of the gradient and of the loss ---------------------------------
+    // rim rows 64..68 (lane (gm, gs < 5) finishes row 64 + gs of component gm; w = P_BA theta_A from the matrix cores):
+    //   y_B = w + P_BB theta_B - c_B
+    //   rim share of d^T P d = theta_B (P_BA d_A) + d_B y_B,   P_BA d_A = w - P_BA mu_A
+    const int tBoff = XS_BODY + NC + (gs < NR ? gs : 0);
     float gp0[FW], gp1[FW], lossp[FW], bestv[FW];
     auto row_prior = [&](bool last) __attribute__((always_inline)) {
 #pragma unroll
@@ -623,22 +624,31 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         const float* xs = slots + slot * SLOT;
         float yA = 0.f, yBs = 0.f, best = 0.f;
         if (use_gmm) {
-            const float q = qrim[h] + qx[slot * MG + gm];        // lanes 8m..8m+7: d^T P d of component m
-            const float val = 0.5f * q + a.neg_log_nllw[gm < M ? gm : 0];
-            best = read_lane(val, 0);
-            int mstar = 0;
-#pragma unroll
-            for (int m = 1; m < MG; ++m) {
-                const float vm = read_lane(val, 8 * m);
-                if (m < M && vm < best) { best = vm; mstar = m; }
+            const float4 t64 = *reinterpret_cast<const float4*>(xs + XS_BODY + NC);      // theta_B[0..3]
+            const float t68 = xs[XS_BODY + NC + 4];
+            float yBv, qrim;
+            {
+                const float wm = wx[slot * 64 + lane], tB = xs[tBoff];
+                const float vB = pbb[0] * t64.x + pbb[1] * t64.y + pbb[2] * t64.z + pbb[3] * t64.w + pbb[4] * t68;
+                const float y = wm + vB - cB;
+                const float term = tB * (wm - kB) + (tB - muB) * y;
+                yBv = gs < NR ? y : 0.f;
+                qrim = group8_sum(gs < NR ? term : 0.f);         // every lane of group gm: rim share of component gm
             }
+            const float q = qrim + qx[slot * MG + gm];           // lanes 8m..8m+7: d^T P d of component m
+            float val = 0.5f * q + a.neg_log_nllw[gm < M ? gm : 0];
+            val = gm < M ? val : __builtin_inff();               // (components beyond M never win)
+            // arg-min over the eight lane groups: a wave-wide minimum (one DPP step inside the rows of 16, two permlane
+            // swaps across them), then the lowest lane that holds it - the first minimum wins, as torch.min and the
+            // eight-readlane compare chain this replaces (55 instructions per frame against 14)
+            best = group8_wave_min(val);
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(val == best);
+            const int mstar = hit ? (int)(__builtin_ctzll(hit) >> 3) : 0;
             // rows 0..63: core part from the component wave + the rim columns, P[l][64 + c] = P[64 + c][l]
             yA = yx[slot * YX_STRIDE + mstar * NC + lane];
-            const float4 t64 = *reinterpret_cast<const float4*>(xs + XS_BODY + NC);
-            const float t68 = xs[XS_BODY + NC + 4];
             const float* rimf = lds + mstar * 32 + rimcol;
             yA += rimf[0 * 512] * t64.x + rimf[1 * 512] * t64.y + rimf[2 * 512] * t64.z + rimf[3 * 512] * t64.w + rimf[4 * 512] * t68;
-            yBs = bperm((8 * mstar + (lane < NR ? lane : 0)) * 4, yB[h]);   // rows 64 + lane for lanes < 5
+            yBs = bperm((8 * mstar + (lane < NR ? lane : 0)) * 4, yBv);     // rows 64 + lane for lanes < 5
         }
         // Branch-free: every lane evaluates  c_y y + 2 c_q (x - ref)  with its own coefficients (set A: mixture
         // + preserve; set B: the same for body_pose[64..68], shape prior for betas, transl prior for transl,
@@ -696,7 +706,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // published].  The roles of the split shape run their own loops, so that the tree waves carry no
     // component registers and the row waves no tree registers.
     if (SPLIT && wave >= 4) {
-        // tree waves: kinematics, joint loss, analytic backward
+        // tree waves: kinematics, joint loss, analytic backward.  They are the iteration's critical path and share their SIMD
+        // with a row wave: raised priority, so that the row wave (and its MFMAs, which hold the SIMD for 16 cycles each) fills
+        // the tree wave's stalls instead of competing for its issue slots
+        __builtin_amdgcn_s_setprio(3);
         const int steps = PAIR ? 1 : a.chain_len;
         for (int step = 0; step < steps; ++step) {
             const int nit = step == 0 ? a.num_iters : a.chain_iters;
@@ -750,12 +763,11 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             const bool last = it == nit - 1;
             if (do_row) publish();
             __syncthreads();
-            floatx4 ya[4], yb[4];
+            floatx4 ya[5], yb[5];
             if (use_gmm) {
-                comp_issue(pa_h, pa_l, ya, PAIR ? wave : -1);
-                comp_issue(pb_h, pb_l, yb, wave + 4);
+                comp_issue(pa_h, pa_l, ya, PAIR ? wave : -1, wave);
+                comp_issue(pb_h, pb_l, yb, wave + 4, wave + 4);
             }
-            if (do_row) rim();
             if (use_gmm) {
                 comp_consume(ya, wave);
                 comp_consume(yb, wave + 4);
@@ -793,9 +805,8 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             const bool last = it == a.num_iters - 1;
             if (do_row) publish();
             __syncthreads();
-            floatx4 ya[4];
-            if (use_gmm) comp_issue(pa_h, pa_l, ya, wave);
-            if (do_row) rim();                          // the matrix pipe runs under the rim's vector work
+            floatx4 ya[5];
+            if (use_gmm) comp_issue(pa_h, pa_l, ya, wave, wave);
             if (use_gmm) comp_consume(ya, wave);        // consumed before the tree, whose registers are then free
             if (do_tree) tree_pass(last);
             __syncthreads();

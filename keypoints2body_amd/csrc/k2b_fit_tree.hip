@@ -46,7 +46,7 @@ template <int NS, bool CHAIN>            // NS: capacity for shape coefficients 
 __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tlds[];
     // [8][16][64] half8 A fragments (128 KiB) | [M][64] h | [M][64] b | [M][64] mu | [TW][64] theta_v fp32 |
-    // [TW][hi 64 | lo 64] theta_v f16 | [TW][M][64] y' | [TW][M] q
+    // [TW][hi 64 | lo 64] theta_v f16 | [TW][M][64] y' | [TW][M] q | [M] constants | [M] 1 / scale
     const half8* const sFrag = reinterpret_cast<const half8*>(tlds);
     float* const sH = tlds + TMG * 16 * 64 * 4;
     float* const sB = sH + TMG * 64;
@@ -54,7 +54,9 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
     float* const sTh = sMu + TMG * 64;
     _Float16* const sTh16 = reinterpret_cast<_Float16*>(sTh + TW * 64);
     float* const sY = sTh + TW * 64 + TW * 64;           // (TW x 128 halfs = TW x 64 floats)
-    float* const sQ = sY + TW * TMG * 64;
+    float* const sQ = sY + TW * TMG * 64;                // 0.5 q + (0.5 c_m - log nll weight): what the arg-min compares
+    float* const sPcl = sQ + TW * TMG;                   // [M] that constant | [M] 1 / fragment scale - read from LDS, not from
+    float* const sIsc = sPcl + TMG;                      //  global memory, inside the iteration (k2b_fit.hip has the story)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         for (int i = threadIdx.x; i < TMG * 16 * 64; i += blockDim.x)
             reinterpret_cast<float4*>(tlds)[i] = reinterpret_cast<const float4*>(a.pfrag)[i];
     for (int i = threadIdx.x; i < TMG * 64; i += blockDim.x) { sH[i] = a.ph[i]; sB[i] = a.pb[i]; sMu[i] = a.pmu[i]; }
+    if (threadIdx.x < TMG) { sPcl[threadIdx.x] = a.pcl[threadIdx.x]; sIsc[threadIdx.x] = a.inv_scale[threadIdx.x]; }
     __syncthreads();
 
     if (comp_role) {
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
                 const half8* fi = reinterpret_cast<const half8*>(a.pfrag) + (size_t)(((cw + 4 * o) * 4 + t) * 4) * 64 + lane;
                 fh[o][t][0] = fi[0]; fh[o][t][1] = fi[64]; fl[o][t][0] = fi[128]; fl[o][t][1] = fi[192];
             }
+        const float isc[2] = {sIsc[cw], sIsc[cw + 4]}, pcl[2] = {sPcl[cw], sPcl[cw + 4]};
         const int steps = CHAIN ? a.chain_len : 1;
         for (int step = 0; step < steps; ++step) {
             const int nit = step == 0 ? a.num_iters : a.chain_iters;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
                     for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[o][t][0], bh0, acc[t], 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[o][t][1], bh1, acc[t], 0, 0, 0);
-                    const float inv_scale = a.inv_scale[c];
+                    const float inv_scale = isc[o];
                     float qp = 0.f;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
                     }
                     qp = pair_sum32(qp);
                     qp = pair_sum16(qp);
-                    sQ[cslot * TMG + c] = qp;
+                    sQ[cslot * TMG + c] = 0.5f * qp + pcl[o];
                 }
                 asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));   // (B fragments live past the last MFMA, see k2b_fit.hip)
                 __syncthreads();                                   // y' and q published
@@ -232,6 +236,8 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
     const int cn = lane & 15, cg = lane >> 4;    // MFMA lane: column (frame slot of the workgroup) and k / row group
     const int cslot = cn < tw ? cn : tw - 1;     // columns beyond the workgroup's frames repeat the last slot
     for (int it = 0; it < nit; ++it) {
+        const float2 co = a.adam_coef[it];       // requested a whole iteration ahead of its use (at the use it was a global load with a
+                                                 // full wait on the iteration's critical path)
         // ---- body pose in prior layout (lane i = prior dimension i); published for the component role ------------------------------
         float thv;
         {
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             const half8 bl0 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 64 + 8 * cg);
             const half8 bl1 = *reinterpret_cast<const half8*>(sTh16 + cslot * 128 + 96 + 8 * cg);
             for (int c = wave; c < TMG; c += tw) {
-                const float inv_scale = a.inv_scale[c];
+                const float inv_scale = sIsc[c], pcl_c = sPcl[c];
                 float qp = 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
                 }
                 qp = pair_sum32(qp);
                 qp = pair_sum16(qp);                                  // summed over the four row groups
-                sQ[cslot * TMG + c] = qp;
+                sQ[cslot * TMG + c] = 0.5f * qp + pcl_c;
             }
             // keep the B fragments live past the last MFMA (ROCm 7.2 register allocation, see k2b_fit.hip)
             asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             int bm = 0;
 #pragma unroll
             for (int m = 0; m < TMG; ++m) {          // (components beyond M: +inf constant - never the arg-min)
-                const float ell = 0.5f * sQ[wave * TMG + m] + a.pcl[m];
+                const float ell = sQ[wave * TMG + m];
                 const bool lt = ell < best;                      // first minimum wins, as torch.min does
                 best = lt ? ell : best;
                 bm = lt ? m : bm;
@@ -410,7 +416,6 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         loss_total = wave_sum_fast(lj + lsh + lv) + lpr;
 
         // ---- Adam (torch.optim.Adam, single-tensor path; bias terms from the host table) ----------------------------------------------
-        const float2 co = a.adam_coef[it];
         auto adam = [&](float& x, float& mm, float& vv, float gi, bool on) {
             if (!on) return;
             mm = mm + a.one_minus_beta1 * (gi - mm);
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
 hipError_t launch_fit_tree(const FitTreeArgs& a_in, hipStream_t stream) {
     if (a_in.num_frames <= 0) return hipSuccess;
     if (a_in.num_joints > 64 || a_in.num_shape > 32 || a_in.prior_dims > 64 || a_in.num_gauss > TMG) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(TMG * 16 * 64 * 4 + 3 * TMG * 64 + 2 * TW * 64 + TW * TMG * 64 + TW * TMG) * sizeof(float);
+    const size_t lds = (size_t)(TMG * 16 * 64 * 4 + 3 * TMG * 64 + 2 * TW * 64 + TW * TMG * 64 + TW * TMG + 2 * TMG) * sizeof(float);
     // frames per workgroup: enough to cover the batch with one workgroup per CU (up to 8: two waves per SIMD); small
     // batches get fewer waves per CU, so that every SIMD hosts at most one frame and all CUs work
     int dev = 0, cus = 256;
