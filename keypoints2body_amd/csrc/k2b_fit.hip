@@ -91,12 +91,6 @@ __device__ __forceinline__ float group8_sum(float v) {
 }
 
 // minimum over the wave of a value that is uniform inside each group of eight lanes
-// (v_min_f32 in asm: fminf() costs a canonicalising v_max_f32 per operand on top; NaNs lose against numbers either way)
-__device__ __forceinline__ float vmin(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 __device__ __forceinline__ float group8_wave_min(float v) {
     float r;
     asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));

@@ -384,15 +384,13 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         float lpr = 0.f;
         if (use_gmm) {
             if (ncw != 0) __syncthreads();       // component-wave shape: y' and q arrive while this wave ran the tree
-            float best = 3.0e38f;
-            int bm = 0;
-#pragma unroll
-            for (int m = 0; m < TMG; ++m) {          // (components beyond M: +inf constant - never the arg-min)
-                const float ell = sQ[wave * TMG + m];
-                const bool lt = ell < best;                      // first minimum wins, as torch.min does
-                best = lt ? ell : best;
-                bm = lt ? m : bm;
-            }
+            // arg-min over the components (those beyond M carry a 3e38 constant - never the arg-min): lanes 0..7 take one value
+            // each, an 8-lane DPP minimum, then the lowest lane that holds it - the first minimum wins, as torch.min does and as
+            // the chain of eight compare / select steps this replaces
+            const float ell = lane < TMG ? sQ[wave * TMG + lane] : 3.0e38f;
+            const float best = read_lane(vmin(group8_min(ell), 3.0e38f), 0);
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < TMG && ell == best);
+            const int bm = hit ? (int)__builtin_ctzll(hit) : 0;
             const float yb = sY[(wave * TMG + bm) * 64 + lane];
             gv = isP ? wpp * yb : 0.f;
             lpr = wpp * best;

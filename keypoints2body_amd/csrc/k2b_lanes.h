@@ -67,6 +67,23 @@ __device__ __forceinline__ float lane_xor4(float v) {                           
 __device__ __forceinline__ float pair_sum32(float v) { float a = v, b = v; swap32(a, b); return a + b; }
 __device__ __forceinline__ float pair_sum16(float v) { float a = v, b = v; swap16(a, b); return a + b; }
 
+// v_min_f32 as asm: fminf() costs a canonicalising v_max_f32 per operand on top; NaNs lose against numbers either way
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// minimum over the lane's group of eight {l ^ 1, l ^ 2, l ^ 4}: quad_perm twice, then the half-row mirror (the s_nop covers the
+// two wait states between a VALU write and a DPP read of the same register, which hipcc does not insert inside asm)
+__device__ __forceinline__ float group8_min(float v) {
+    float r;
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum_fast(float v) {
     v = pair_sum32(v);
     v = pair_sum16(v);
