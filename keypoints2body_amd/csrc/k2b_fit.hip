@@ -463,16 +463,22 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         // ---- pointer-doubling down-sweep: after round r a lane is composed with 2^(r+1) ancestors ----
         Mat3 Rg = rod.R;                   // becomes the global rotation
         Vec3 pj = dj;                      // becomes the posed joint (without transl)
+        auto round = [&](int r) __attribute__((always_inline)) {
+            Mat3 Ra;
 #pragma unroll
-        for (int r = 0; r < kMaxRounds; ++r) {
-            if (r < a.num_rounds) {
-                Mat3 Ra;
+            for (int i = 0; i < 9; ++i) Ra.m[i] = bperm(anc_addr[r], Rg.m[i]);
+            const Vec3 da = {bperm(anc_addr[r], pj.x), bperm(anc_addr[r], pj.y), bperm(anc_addr[r], pj.z)};
+            pj = mul(Ra, pj) + da;
+            Rg = mul(Ra, Rg);
+        };
+        // straight-line code for the two common depths (22 AMASS targets: 3 rounds; all 24 joints: 4) - a conditional round ends in
+        // twelve register copies where its results join the skipped path
+        if (a.num_rounds == 3) { round(0); round(1); round(2); }
+        else if (a.num_rounds == 4) { round(0); round(1); round(2); round(3); }
+        else {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) Ra.m[i] = bperm(anc_addr[r], Rg.m[i]);
-                const Vec3 da = {bperm(anc_addr[r], pj.x), bperm(anc_addr[r], pj.y), bperm(anc_addr[r], pj.z)};
-                pj = mul(Ra, pj) + da;
-                Rg = mul(Ra, Rg);
-            }
+            for (int r = 0; r < kMaxRounds; ++r)
+                if (r < a.num_rounds) round(r);
         }
         // ---- e. joint loss, its gradient, subtree force / torque sums ------------------------------
         // (no branch on "this lane has a target": wconf = 0 there, so its loss and gradient vanish)

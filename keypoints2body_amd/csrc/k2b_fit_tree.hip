@@ -307,16 +307,20 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         // lane 63, which is no joint and holds the identity throughout: no select in the rounds.
         Mat3 Rg = rod.R;
         Vec3 pg = {dx, dy, dz};
+        auto round = [&](int r) __attribute__((always_inline)) {
+            Mat3 pR;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r < a.num_rounds) {
-                Mat3 pR;
+            for (int i = 0; i < 9; ++i) pR.m[i] = bperm(anc[r], Rg.m[i]);
+            const Vec3 pp = {bperm(anc[r], pg.x), bperm(anc[r], pg.y), bperm(anc[r], pg.z)};
+            pg = mul(pR, pg) + pp;
+            Rg = mul(pR, Rg);
+        };
+        if (a.num_rounds == 4) {                 // the full SMPL-X / SMPL-H tree: straight-line code (a conditional round ends in twelve
+            round(0); round(1); round(2); round(3);   // register copies where its results join the skipped path)
+        } else {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) pR.m[i] = bperm(anc[r], Rg.m[i]);
-                const Vec3 pp = {bperm(anc[r], pg.x), bperm(anc[r], pg.y), bperm(anc[r], pg.z)};
-                pg = mul(pR, pg) + pp;
-                Rg = mul(pR, Rg);
-            }
+            for (int r = 0; r < 4; ++r)
+                if (r < a.num_rounds) round(r);
         }
 
         // ---- joint term (losses.py:6-10,49-51) ---------------------------------------------------------------------------------------
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             const float ex = pg.x + t0 - ty0, ey = pg.y + t1 - ty1, ez = pg.z + t2 - ty2;
             const float x2 = ex * ex, y2 = ey * ey, z2 = ez * ez;
             const float qx = s2 + x2, qy = s2 + y2, qz = s2 + z2;
-            lj = wconf * ((s2 * x2) / qx + (s2 * y2) / qy + (s2 * z2) / qz);
+            if (it == nit - 1) lj = wconf * ((s2 * x2) / qx + (s2 * y2) / qy + (s2 * z2) / qz);   // (the loss that leaves is the last iteration's)
             const float k2 = 2.f * wconf * (s2 * s2);
             g = {k2 * ex / (qx * qx), k2 * ey / (qy * qy), k2 * ez / (qz * qz)};
         }
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             const float a0 = shfl(gv, s0i), a1 = shfl(gv, s0i + 1 < 64 ? s0i + 1 : 63), a2 = shfl(gv, s0i + 2 < 64 ? s0i + 2 : 63);
             if (pd0 >= 0) { gth[0] += a0; gth[1] += a1; gth[2] += a2; }
         }
-        loss_total = wave_sum_fast(lj + lsh + lv) + lpr;
+        if (it == nit - 1) loss_total = wave_sum_fast(lj + lsh + lv) + lpr;
 
         // ---- Adam (torch.optim.Adam, single-tensor path; bias terms from the host table) ----------------------------------------------
         auto adam = [&](float& x, float& mm, float& vv, float gi, bool on) {
