@@ -333,19 +333,22 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
             const float qx = s2 + x2, qy = s2 + y2, qz = s2 + z2;
             if (it == nit - 1) lj = wconf * ((s2 * x2) / qx + (s2 * y2) / qy + (s2 * z2) / qz);   // (the loss that leaves is the last iteration's)
             const float k2 = 2.f * wconf * (s2 * s2);
-            g = {k2 * ex / (qx * qx), k2 * ey / (qy * qy), k2 * ez / (qz * qz)};
+            g = {k2 * ex * fast_rcp(qx * qx), k2 * ey * fast_rcp(qy * qy), k2 * ez * fast_rcp(qz * qz)};   // (1-ulp reciprocal, as k2b_fit.hip:
+                                                                                                           //  three IEEE divisions were 33 instructions)
         }
 
         // ---- subtree sums: S = sum g, Mo = sum p x g over the subtree of every joint ----------------------------------------------------
         const Vec3 pxg = cross(pg, g);
         const float v6[6] = {g.x, g.y, g.z, pxg.x, pxg.y, pxg.z};
         float sub[6];
-        const int hi = lane + ssize - 1 < 63 ? lane + ssize - 1 : 63, lo = lane > 0 ? lane - 1 : 0;
+        const int hi = lane + ssize - 1 < 63 ? lane + ssize - 1 : 63;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const double pre = wave_inclusive_scan(isJ ? v6[i] : 0.f, lane);
-            const double up = shfl64(pre, hi), dn = shfl64(pre, lo);
-            sub[i] = (float)(up - (lane > 0 ? dn : 0.0));
+            float v = isJ ? v6[i] : 0.f;
+            asm volatile("" : "+v"(v));                  // (select on the float: behind the conversion it is two selects on the double)
+            const double pre = wave_inclusive_scan(v, lane);
+            const double up = shfl64(pre, hi);           // prefix at the last lane of the subtree
+            sub[i] = (float)(up - (pre - (double)v));    // minus the prefix just before its first lane (this lane): no second fetch
         }
         const Vec3 S = {sub[0], sub[1], sub[2]};
         const Vec3 torque = Vec3{sub[3], sub[4], sub[5]} - cross(pg, S);
