@@ -373,6 +373,20 @@ __global__ __launch_bounds__(64 * TW) void k2b_fit_tree_kernel(const FitTreeArgs
         gsh = 0.f;
 #pragma unroll
         for (int blk = 0; blk < (NS + 15) / 16; ++blk) { // 16 coefficients per butterfly: lane l ends with the total of k = (l >> 2) & 15
+            if constexpr (NS % 16 != 0 && NS % 16 <= 4) {
+                if (blk == NS / 16) {                    // a last block of at most four coefficients (SMPL-X: 16 + 4): a four-value butterfly
+                    float part4[4];                      // instead of a sixteen-value one over twelve zeros
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int kk = 16 * blk + k < NS ? 16 * blk + k : 0;
+                        part4[k] = (16 * blk + k < NS && isJ) ? gd.x * dd[0][kk] + gd.y * dd[1][kk] + gd.z * dd[2][kk] : 0.f;
+                    }
+                    const float tot = butterfly4_sum(part4);                  // row r of 16 lanes: coefficient 16 blk + r
+                    const float mine = shfl(tot, (lane & 3) << 4);
+                    if ((lane >> 4) == blk) gsh = mine;                       // (lanes 16 blk + 4 .. hold no coefficient: masked below)
+                    continue;
+                }
+            }
             float part[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

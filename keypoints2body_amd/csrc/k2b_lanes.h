@@ -121,6 +121,24 @@ __device__ __forceinline__ float butterfly16_sum(const float (&v)[16], int lane)
     return r;
 }
 
+// 4 per-lane values -> every lane of the 16-lane row r ends with the wave-wide sum of v[r]
+__device__ __forceinline__ float butterfly4_sum(const float (&v)[4]) {
+    float w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float a = v[i], b = v[2 + i];
+        swap32(a, b);
+        w[i] = a + b;                // lanes < 32: v[i] over the lane pair; lanes >= 32: v[2 + i]
+    }
+    float a = w[0], b = w[1];
+    swap16(a, b);
+    float r = a + b;                 // even rows: w[0]; odd rows: w[1]
+    r += lane_xor8(r);
+    r += lane_xor4(r);
+    r += lane_xor2(r);
+    r += lane_xor1(r);
+    return r;
+}
 
 // inclusive prefix sum over all 64 lanes, in double: the two half-wave scans plus the lower half's total
 __device__ __forceinline__ double wave_inclusive_scan(float v, int lane) {
