@@ -140,13 +140,16 @@ __device__ __forceinline__ float butterfly4_sum(const float (&v)[4]) {
     return r;
 }
 
-// inclusive prefix sum over all 64 lanes, in double: the two half-wave scans plus the lower half's total
+// inclusive prefix sum over all 64 lanes, in double: the two half-wave scans, then the lower half's total (lane 31) added to the
+// upper half with one more DPP step (row_bcast:31 into rows 2, 3)
 __device__ __forceinline__ double wave_inclusive_scan(float v, int lane) {
-    const double s = half_wave_inclusive_scan(v);
+    (void)lane;
+    double s = half_wave_inclusive_scan(v);
     const long long bits = __builtin_bit_cast(long long, s);
-    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), 31), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 31);
-    const double carry = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-    return lane >= 32 ? s + carry : s;
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), 0x143, 0xc, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), 0x143, 0xc, 0xf, true);
+    s += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    return s;
 }
 
 }  // namespace k2b
