@@ -66,6 +66,12 @@ template <int OFF>
 __device__ __forceinline__ void lread16(half8& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
+// 12-byte store through a scalar row base and a per-lane 32-bit byte offset (the compiler's own code adds 64-bit vector addresses
+// per store; nobody waits for a store except the end of the kernel)
+typedef float float3r __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void gstore12(unsigned lane_off, float3r d, const void* sbase) {
+    asm volatile("global_store_dwordx3 %0, %1, %2" ::"v"(lane_off), "v"(d), "s"(sbase) : "memory");
+}
 #define K2B_LDS_READY2(N, b) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory")
 
 struct Walk {                  // (frame group, vertex group) tiles of this workgroup, XCD-aware: see TileWalk in k2b_lbs.hip
@@ -244,8 +250,10 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
         int jrow = 0;
         bool has_joint = false;
         const size_t row_bytes = (size_t)a.out_stride * 12;                     // one frame of the output
-        // this lane's (vertex, first frame 4 g of unit 0) in the output; rows of the unit's other frames are uniform offsets from it
-        unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + ((size_t)a.out_row0 + v) * 12 + (size_t)(cfg * 128 + 4 * g) * row_bytes;
+        // a store address = wave-uniform row base (tile's first frame + u 16 + i, scalar arithmetic) + this lane's 32-bit offset
+        // (its vertex, and the frames 4 g .. of its k-group): global_store with a scalar base, no 64-bit vector arithmetic per store
+        unsigned char* const tbase = reinterpret_cast<unsigned char*>(a.out) + (size_t)(cfg * 128) * row_bytes;
+        const unsigned voff = (unsigned)(((size_t)a.out_row0 + v) * 12 + (size_t)(4 * g) * row_bytes);
         const bool tile_full = cfg * 128 + 127 < a.num_frames && (cvg * 8 + wave) * 16 + 15 < a.num_out;   // wave-uniform
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][1], wf[1], acc, 0, 0, 0);
                     t[n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[n & 1][0], wf[2], acc, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);     // the fold of entry n - 1 behind all three MFMAs of entry n: no hazard no-ops on t
                 if constexpr (n > 0) {
                     constexpr int d = (n - 1) / 3, r = (n - 1) % 3;
                     // element by element: written on the 4-vectors this becomes v_pk_fma_f32 / v_pk_add_f32, which issue at well under
@@ -308,18 +317,12 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
             const int fbase = (cfg * 8 + u) * 16 + 4 * g;
             if (tile_full) {                           // every (frame, vertex) of the tile exists: lane base + a wave-uniform row offset
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float3v x;
-                    x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
-                    *reinterpret_cast<float3v*>(obase + (size_t)(u * 16 + i) * row_bytes) = x;
-                }
+                for (int i = 0; i < 4; ++i) gstore12(voff, float3r{out[0][i], out[1][i], out[2][i]}, tbase + (size_t)(u * 16 + i) * row_bytes);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int f = fbase + i;
-                    float3v x;
-                    x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
-                    if (okv && f < a.num_frames) *reinterpret_cast<float3v*>(obase + (size_t)(u * 16 + i) * row_bytes) = x;
+                    if (okv && f < a.num_frames) gstore12(voff, float3r{out[0][i], out[1][i], out[2][i]}, tbase + (size_t)(u * 16 + i) * row_bytes);
                 }
             }
             if (has_joint) {                           // rare (21 of 6890 vertices): the vertex again, into the joints array
