@@ -244,6 +244,52 @@ def test_ill_conditioned_prior_matches_oracle():
     np.testing.assert_allclose(out["loss"].cpu().numpy(), ref.loss.numpy(), rtol=2e-4)
 
 
+@pytest.mark.parametrize("shape", [1, 2, 3])
+def test_rim_heavy_prior_matches_oracle_in_every_shape(shape):
+    """Rows 64..68 of every precision matrix ride on the matrix cores as a fifth row tile whose f16 fragments share the
+    component's power-of-two scale (k2b_api.hip, k2b_fit.hip).  Here the last five pose dimensions are near-linear functions
+    of the first 64 (x_B = C x_A + noise of variance 1e-4), so P_BA = -C / sigma^2 carries entries as large as anything in the
+    core and P_BB = I / sigma^2 the largest of all: the fit must still follow the CPU float32 arithmetic of the reference's
+    formulation (oracle) within the parity budget, in each launch shape."""
+    from keypoints2body_amd import native, synthetic
+    from keypoints2body_amd.native import NativePrior
+    from oracle.fit_torch import GMMPrior, fit_world_adam
+    rng = np.random.default_rng(23)
+    M = 8
+    means = 0.2 * rng.standard_normal((M, 69))
+    covars = np.zeros((M, 69, 69))
+    for m in range(M):
+        A = rng.standard_normal((64, 10)) * 0.05
+        S = A @ A.T + np.diag(10.0 ** rng.uniform(-3.0, -1.0, 64))
+        C = 0.3 * rng.standard_normal((5, 64)) / 8.0
+        covars[m, :64, :64] = S
+        covars[m, 64:, :64] = C @ S
+        covars[m, :64, 64:] = (C @ S).T
+        covars[m, 64:, 64:] = C @ S @ C.T + 1e-4 * np.eye(5)
+    prior_o = GMMPrior(means, covars, np.full(M, 1.0 / M))
+    P = prior_o.precisions.numpy()
+    assert np.abs(P[:, 64:, :64]).max() > 0.05 * np.abs(P[:, :64, :64]).max() and np.abs(P[:, 64:, 64:]).max() > 5e3
+    prior_n = NativePrior(prior_o.means.numpy(), P, prior_o.nll_weights.numpy().reshape(-1))
+    B, iters = 5, 25
+    p = synthetic.make_poses(B, seed=11)
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32)
+    oracle = H.oracle_model()
+    with torch.no_grad():
+        j3d = oracle(global_orient=t(p.global_orient), body_pose=t(p.body_pose), betas=t(p.betas), transl=t(p.transl)).joints[:, :22]
+    go0, bp0, be0, tr0 = t(p.global_orient) * 0.8, t(p.body_pose) * 0.8, torch.zeros(B, 10), t(p.transl) + 0.01
+    ref = fit_world_adam(oracle, prior_o, go0, bp0, be0, tr0, j3d, num_iters=iters)
+    cfg = native.default_fit_config(); cfg.num_iters = iters; cfg.debug_launch_shape = shape
+    out = native.fit_world(H.native_model(), prior_n, cfg, list(range(22)), j3d.cuda().contiguous(), None,
+                           go0.cuda(), bp0.cuda(), be0.cuda(), tr0.cuda())
+    worst = 0.0
+    for key, want in (("global_orient", ref.global_orient), ("body_pose", ref.body_pose), ("betas", ref.betas), ("transl", ref.transl)):
+        err = (out[key].cpu() - want).abs().max().item()
+        worst = max(worst, err)
+        assert err < PARAM_TOL, (shape, key, err)
+    np.testing.assert_allclose(out["loss"].cpu().numpy(), ref.loss.numpy(), rtol=2e-4)
+    print(f"rim-heavy prior, shape {shape}: worst parameter deviation {worst:.2e}")
+
+
 def test_underflowed_mixture_weight_is_never_selected():
     """A mixture weight that underflows to 0 in float32 gives log(0) = -inf in the reference (prior.py:189):
     that component can never be the arg-min.  Same here: with component 0's weight set to 0 the result equals
