@@ -409,21 +409,45 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
         const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
         const half8 bl1 = *reinterpret_cast<const half8*>(cth_lo + 32 + 8 * cg);
+        const half8* rf = rimfrag + comp * kPriorRimFragEntries + ridx;
+        const half8 rh0 = rf[0], rl0 = rf[21], rh1 = rf[42], rl1 = rf[63];   // rim rows 64..68 as a fifth row tile (rows 69..79 are zero)
+        if constexpr (MODE == MODE_SPLIT) {
+            // Step-major over the five row tiles: five independent accumulation chains advance together, so a dependent MFMA never
+            // waits for its predecessor's result.  The split shapes' row waves carry two components and their chain - not the tree's -
+            // is the iteration's critical path at <= 4 frames per CU (stamps: DESIGN.md 4.1): -2.7 % at 1024 frames; in the two-frames-
+            // per-wave shapes the same order is +0.8 % (paired) and +2.2 % (split-paired), so they keep the tile-major one.  Every tile's
+            // own chain has the same order in both: the results are bit-identical.
+            const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][0], bh0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][1], bh1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bl0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bl1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bh0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bh1, acc, 0, 0, 0);
-            yacc[t] = acc;
-        }
-        {   // fifth row tile: the rim rows 64..68 over the core columns (rows 69..79 are zero) - on the vector ALU this was 40 FMAs
-            // and 15 DPP adds per frame; here it is six more MFMAs per component for all sixteen frame columns
-            const half8* rf = rimfrag + comp * kPriorRimFragEntries + ridx;
-            const half8 rh0 = rf[0], rl0 = rf[21], rh1 = rf[42], rl1 = rf[63];
+            for (int t = 0; t < 4; ++t) yacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][0], bh0, z4, 0, 0, 0);
+            yacc[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl0, bh0, z4, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) yacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][1], bh1, yacc[t], 0, 0, 0);
+            yacc[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl1, bh1, yacc[4], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) yacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bl0, yacc[t], 0, 0, 0);
+            yacc[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bl0, yacc[4], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) yacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bl1, yacc[t], 0, 0, 0);
+            yacc[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bl1, yacc[4], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) yacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bh0, yacc[t], 0, 0, 0);
+            yacc[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bh0, yacc[4], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) yacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bh1, yacc[t], 0, 0, 0);
+            yacc[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bh1, yacc[4], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][0], bh0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[t][1], bh1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bl0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bl1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bh0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bh1, acc, 0, 0, 0);
+                yacc[t] = acc;
+            }
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl0, bh0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl1, bh1, acc, 0, 0, 0);
