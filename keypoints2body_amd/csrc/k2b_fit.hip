@@ -50,6 +50,17 @@
 #include "k2b_internal.h"
 #include "k2b_lanes.h"
 
+// Per-phase s_memtime stamps of the split shape's two roles live outside this file: tools/build_fit_stamps.sh compiles it with
+// -DK2B_FIT_DIAG_HEADER=<tools/fit_diag.h>, which fills the hooks below (iteration 50 of one workgroup, device printf behind the loop).
+#ifdef K2B_FIT_DIAG_HEADER
+#include K2B_FIT_DIAG_HEADER
+#else
+#define K2B_FSTAMP_DECL ((void)0)
+#define K2B_FSTAMP(i) ((void)0)
+#define K2B_FSTAMP_TREE_PRINT ((void)0)
+#define K2B_FSTAMP_ROW_PRINT ((void)0)
+#endif
+
 namespace k2b {
 
 namespace {
@@ -744,11 +755,17 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 const float c = a.conf ? a.conf[(a.conf_per_frame ? ft * a.num_targets : 0) + tk] : 1.0f;
                 wconf = (a.joint_w * a.joint_w) * (c * c);
             }
+            K2B_FSTAMP_DECL;
             for (int it = 0; it < nit; ++it) {
+                K2B_FSTAMP(0);
                 __syncthreads();
+                K2B_FSTAMP(1);
                 if (do_tree) tree_pass(it == nit - 1);
+                K2B_FSTAMP(2);
                 __syncthreads();
+                K2B_FSTAMP(3);
             }
+            K2B_FSTAMP_TREE_PRINT;
         }
         return;
     }
@@ -783,15 +800,20 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 if (bodyB) { pr1[0] = x1[0]; refB[0] = x1[0]; }
                 m0[0] = v0[0] = m1[0] = v1[0] = 0.f;
             }
+        K2B_FSTAMP_DECL;
         for (int it = 0; it < nit; ++it, ++git) {
             const bool last = it == nit - 1;
+            K2B_FSTAMP(0);
             if (do_row) publish();
+            K2B_FSTAMP(1);
             __syncthreads();
+            K2B_FSTAMP(2);
             floatx4 ya[5], yb[5];
             if (use_gmm) {
                 comp_issue(pa_h, pa_l, ya, PAIR ? wave : -1, wave);
                 comp_issue(pb_h, pb_l, yb, wave + 4, wave + 4);
             }
+            K2B_FSTAMP(3);
             if (use_gmm) {
                 comp_consume(ya, wave);
                 comp_consume(yb, wave + 4);
@@ -799,14 +821,20 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
                 // (release after their y / q writes, acquire before reading the others') so that the
                 // arg-min and the priors' gradient are done while the tree waves still work, and only
                 // "add the joint gradient, Adam, publish" is left on the iteration's critical path
+                K2B_FSTAMP(4);
                 if (lane == 0) __hip_atomic_fetch_add(row_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int target = 4 * (git + 1);
                 while (__hip_atomic_load(row_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
+            K2B_FSTAMP(5);
             if (do_row) row_prior(last);
+            K2B_FSTAMP(6);
             __syncthreads();
+            K2B_FSTAMP(7);
             if (do_row) row_finish(it, last);
+            K2B_FSTAMP(8);
         }
+        K2B_FSTAMP_ROW_PRINT;
             if (!PAIR && chain && do_row && f_valid[0]) {     // this step's frame: row s chain_len + step
                 const size_t fr = (size_t)f[0] * a.chain_len + step;
                 *out_ptr_c(fr, pA) = x0[0];
