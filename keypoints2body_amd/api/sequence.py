@@ -61,11 +61,11 @@ def _fit_independent_frames(est, prev: BodyModelParams, xyz, conf, model_indices
     results of other ranks' frames - unless ``gather_vertices`` asks for the second exchange.
 
     Returns ``(params dict over all T frames, joints (T, .), vertex_of(i) -> (1, V, 3) | None, loss (T,))``."""
-    from ..parallel import fit_forward_exchange, shard_bounds, unpack_outputs, valid_rows
+    from ..parallel import fit_forward_exchange, rows_per_rank, shard_bounds, unpack_outputs, valid_rows
     T = xyz.shape[0]
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
     start, stop = shard_bounds(T, world, rank)
-    per = (T + world - 1) // world
+    per = rows_per_rank(T, world)
     pose_dim, num_shape = _packed_widths(est, prev)
     device = xyz.device
 
@@ -80,7 +80,7 @@ def _fit_independent_frames(est, prev: BodyModelParams, xyz, conf, model_indices
             o, _, _, _ = est.fit_batch(_repeat_params(prev, stop - lo), xyz[lo:stop], conf[lo:stop], seq_ind=1,
                                        target_model_indices=model_indices, per_frame_conf=True, run_forward=False)
             parts.append(o)
-        if not parts:                                     # empty trailing shard: zero rows of the right widths
+        if not parts:                                     # more ranks than frames: this rank has no frame - zero rows of the right widths
             e = lambda c: torch.zeros((0, c), dtype=torch.float32, device=device)
             return {"global_orient": e(3), "body_pose": e(pose_dim), "betas": e(num_shape), "transl": e(3),
                     "loss": torch.zeros((0,), dtype=torch.float32, device=device)}
@@ -89,8 +89,8 @@ def _fit_independent_frames(est, prev: BodyModelParams, xyz, conf, model_indices
         return {k: torch.cat([p[k] for p in parts], dim=0).contiguous() for k in parts[0]}
 
     def forward_block(out):
-        if out["loss"].shape[0] == 0:
-            return None, None
+        # (also for a rank without frames: the forward of zero rows returns zero-row joints / vertices, and the rank enters
+        #  every collective of the exchange with padding only - never branch a collective on what a block holds)
         return est.fitter.final_forward(out)
 
     ex = fit_forward_exchange(fit_block, forward_block, dist, pad_to=per, gather_vertices=gather_vertices)
@@ -100,8 +100,6 @@ def _fit_independent_frames(est, prev: BodyModelParams, xyz, conf, model_indices
     keep = valid_rows(T, world, device)
     out = unpack_outputs(ex["packed"].index_select(0, keep), num_shape, pose_dim)
     joints, verts = ex["joints"], ex["vertices"]
-    if joints is None:                                    # this rank's shard was empty: it still receives everyone's joints
-        raise RuntimeError("more ranks than frames: every rank must own at least one frame of the sequence")
     joints = joints.index_select(0, keep)
     if ex["vertices_gathered"]:
         verts = verts.index_select(0, keep)

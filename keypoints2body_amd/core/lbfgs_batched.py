@@ -42,9 +42,10 @@ def _cubic(x1, f1, g1, x2, f2, g2, lo=None, hi=None):
         fwd = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2.0 * d2))
         bwd = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2.0 * d2))
     pos = np.where(x1 <= x2, fwd, bwd)
-    # min(max(pos, lo), hi) with Python semantics for NaN (a NaN position falls through to the bounds like in torch)
-    pos = np.where(pos > lo, pos, lo)
-    pos = np.where(pos < hi, pos, hi)
+    # torch: min(max(pos, lo), hi) on Python floats, where max(a, b) is "b if b > a else a": a NaN position STAYS NaN (every
+    # comparison with it is false), the step becomes NaN, the next loss is not finite and the frame stops - same here
+    pos = np.where(lo > pos, lo, pos)
+    pos = np.where(hi < pos, hi, pos)
     return np.where(sq >= 0, pos, 0.5 * (lo + hi))
 
 

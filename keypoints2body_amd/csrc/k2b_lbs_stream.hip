@@ -200,10 +200,11 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
         };
         xread(xq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         // younger than the awaited loads at each wait (in issue order): see the table in DESIGN.md 4.2
-        // k-step 0 was loaded during the previous tile's pose phase: more than 63 operations of the transform phase are younger, so
-        // "at most 63 outstanding" (the counter's ceiling) already means it has landed - and does NOT wait for the transform
-        // phase's last stores, whose acknowledgements take thousands of cycles when every CU writes at once (stores and loads share
-        // the counter and retire in order).  (First tile: the prologue waited for everything.)
+        // k-steps 0 and 1 were loaded during the previous tile's pose phase, in front of A(unit 1): the wait of the previous tile's
+        // unit 1 has covered them already (whether or not that tile stored), so nothing is left to wait for here - vmcnt(63), the
+        // counter's ceiling, only ties the registers to this point and does NOT wait for the transform phase's last stores, whose
+        // acknowledgements take thousands of cycles when every CU writes at once (stores and loads share the counter and retire
+        // in order).  (First tile: the prologue waited for everything.)
         K2B_PD_READY(63, pb0);
         load_pd(pb2, cvg, 2);                        // Pd two k-steps ahead
         kstep(std::integral_constant<int, 0>{}, pb0);
@@ -261,8 +262,13 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
             // younger: the previous unit's 2 X fills + 4 stores (unit 0: the 6 Pd loads of the next tile's k-step 1; unit 7: stores only,
             // because the last X fills must be visible to every wave before the next pose phase)
             K2B_SDIAG_STAMP(8 + 3 * u);
+            // The stores of a unit are part of the count ONLY where every one of them is issued: in the predicated path a wave whose
+            // lanes are all beyond the mesh or the batch skips the instruction (s_cbranch_execz), so a wave of a partial tile counts
+            // the fills alone (tile_full is wave-uniform: a scalar branch).  Fewer younger operations than N would leave the awaited
+            // fills in flight; more (the rare joint copies) only make the wait stricter.
             if (u == 0) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2])::"memory");   // (W: loaded at k-step 6, in front of the next tile's k-step 1)
-            else if (u == 7) wait_vmcnt<4>(); else wait_vmcnt<6>();
+            else if (u == 7) { if (tile_full) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+            else { if (tile_full) wait_vmcnt<6>(); else wait_vmcnt<2>(); }
             wg_barrier();
             K2B_SDIAG_STAMP(9 + 3 * u);
             if (u == 0 && a.joints_out) {              // (W fragments are long there: they are older than everything waited for)

@@ -26,10 +26,17 @@ PARAM_KEYS = ("global_orient", "body_pose", "betas", "transl")
 
 
 def shard_bounds(num_frames: int, world_size: int, rank: int) -> Tuple[int, int]:
-    """Contiguous block [start, stop) of ceil(T / G) frames for `rank` (last ranks may be short or empty)."""
-    per = (num_frames + world_size - 1) // world_size
-    start = min(rank * per, num_frames)
-    return start, min(start + per, num_frames)
+    """Contiguous block [start, stop) of `rank`, balanced: the first T mod G ranks own ceil(T / G) frames, the others
+    floor(T / G) - so no rank is empty unless T < G (the ceil-only rule left trailing ranks without frames already at
+    T = 4 on 3 ranks).  Every block is at most ``rows_per_rank`` long, which is what the exchanges pad to."""
+    base, extra = divmod(num_frames, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def rows_per_rank(num_frames: int, world_size: int) -> int:
+    """Rows every rank contributes to an all-gather of per-frame tensors (the longest block; shorter ones are zero-padded)."""
+    return (num_frames + world_size - 1) // world_size
 
 
 def pack_outputs(out: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -92,10 +99,17 @@ def gather_rows(t: torch.Tensor, dist, pad_to: int, async_op: bool = False):
 
 def valid_rows(num_frames: int, world: int, device=None) -> torch.Tensor:
     """Indices of the real frames inside a gathered ``(world * ceil(T / world), ...)`` tensor (padding rows dropped)."""
-    per = (num_frames + world - 1) // world
+    per = rows_per_rank(num_frames, world)
     idx = [torch.arange(r * per, r * per + (shard_bounds(num_frames, world, r)[1] - shard_bounds(num_frames, world, r)[0]))
            for r in range(world)]
     return torch.cat(idx).to(device) if idx else torch.zeros((0,), dtype=torch.long, device=device)
+
+
+def _rows_tensor(t, name: str) -> torch.Tensor:
+    if t is None:
+        raise RuntimeError(f"fit_forward_exchange: the forward returned no {name} although their exchange was requested "
+                           "(an empty block must return a zero-row tensor, so that every rank enters the collective)")
+    return t
 
 
 def fit_forward_exchange(fit_fn: Callable[[], Dict[str, torch.Tensor]], forward_fn, dist=None, pad_to: Optional[int] = None,
@@ -111,9 +125,15 @@ def fit_forward_exchange(fit_fn: Callable[[], Dict[str, torch.Tensor]], forward_
          (a second, separately reported exchange: SURVEY §8e), otherwise every rank keeps the vertices of its own block;
       5. wait for the collectives (stream-ordered: the host is not blocked).
 
-    `pad_to` = rows every rank contributes (ceil(T / world); shards may be short or empty).  Returns a dict: ``local``
-    (this rank's fit outputs), ``packed`` (world * pad_to, P + 1) or None for one rank, ``joints`` (gathered, or local),
-    ``vertices`` (local block, or gathered), ``vertices_gathered``.
+    `pad_to` = rows every rank contributes (ceil(T / world); shards may be short or - with more ranks than frames - empty).
+    Returns a dict: ``local`` (this rank's fit outputs), ``packed`` (world * pad_to, P + 1) or None for one rank, ``joints``
+    (gathered, or local), ``vertices`` (local block, or gathered), ``vertices_gathered``.
+
+    Which collectives run is decided by the ARGUMENTS alone (`gather_joints`, `gather_vertices`), never by what this rank's
+    block holds: a rank without frames fits and forwards ZERO rows (`fit_fn` / `forward_fn` must return zero-row tensors of the
+    usual trailing shapes then, not None) and enters every all-gather with padding only.  A `forward_fn` that returns None
+    for a tensor an exchange was asked for is a programming error and raises BEFORE the first collective is entered only if
+    every rank sees it; so do not make that depend on the data.
     """
     out = fit_fn()
     world, _ = _world(dist)
@@ -124,12 +144,12 @@ def fit_forward_exchange(fit_fn: Callable[[], Dict[str, torch.Tensor]], forward_
     packed, work = gather_fit_outputs(out, dist, pad_to=rows, async_op=True)
     joints, verts = forward_fn(out)
     works = [work]
-    if gather_joints and joints is not None:
-        joints, w = gather_rows(joints, dist, rows, async_op=True)
+    if gather_joints:
+        joints, w = gather_rows(_rows_tensor(joints, "joints"), dist, rows, async_op=True)
         works.append(w)
     gathered_v = False
-    if gather_vertices and verts is not None:
-        verts, w = gather_rows(verts, dist, rows, async_op=True)
+    if gather_vertices:
+        verts, w = gather_rows(_rows_tensor(verts, "vertices"), dist, rows, async_op=True)
         works.append(w)
         gathered_v = True
     for w in works:
@@ -148,7 +168,7 @@ def fit_frames_sharded(fit_fn: Callable[[slice], Dict[str, torch.Tensor]], num_f
     """
     world, rank = _world(dist)
     start, stop = shard_bounds(num_frames, world, rank)
-    per = (num_frames + world - 1) // world
+    per = rows_per_rank(num_frames, world)
     out = fit_fn(slice(start, stop))
     gathered = gather_fit_outputs(out, dist if world > 1 else None, pad_to=per)
     if world > 1:

@@ -97,3 +97,36 @@ def test_lockstep_lbfgs_stops_like_torch():
     assert np.abs(x[1] - xstar[1]).max() < 1e-3       # (xstar is converged to the optimiser's own tolerance, not exactly)
     assert opt.rounds <= 30 * 5 // 4 + 1
     assert np.all(fg(x)[0] <= fg(x0b)[0] + 1e-12)
+
+
+def test_cubic_interpolation_keeps_a_nan_like_torch():
+    """torch's ``min(max(pos, lo), hi)`` on Python floats leaves a NaN position NaN (every comparison with it is
+    false); clamping it to the lower bound instead would make a degenerate line search diverge from ``torch.optim.LBFGS``."""
+    from torch.optim.lbfgs import _cubic_interpolate
+    from keypoints2body_amd.core.lbfgs_batched import _cubic
+    # (x1, f1, g1, x2, f2, g2); the third case is 0 / 0 behind a non-negative discriminant: the one way to a NaN position
+    cases = [(0.0, 1.0, -1.0, 1.0, 0.5, 0.3), (0.0, 1.0, -1.0, 1.0, float("nan"), 0.3), (0.0, 1.0, 0.0, 1.0, 1.0, 0.0),
+             (0.0, 1.0, -1.0, 2.0, 3.0, 4.0), (2.0, 1.0, 1.0, 0.5, 0.7, -0.2)]
+    td = lambda v: torch.tensor(v, dtype=torch.float64)
+    assert np.isnan(float(_cubic_interpolate(0.0, 1.0, td(0.0), 1.0, 1.0, td(0.0))))
+    for c in cases:
+        want = float(_cubic_interpolate(c[0], c[1], td(c[2]), c[3], c[4], td(c[5])))
+        got = float(_cubic(*[np.array([v]) for v in c])[0])
+        assert (np.isnan(want) and np.isnan(got)) or abs(want - got) < 1e-12, (c, want, got)
+
+
+def test_a_frame_with_a_non_finite_loss_stops_and_leaves_the_others_alone():
+    fg, x0 = _problems(5, 12, np.float64, seed=3)
+
+    def fg_bad(X):
+        f, g = fg(X)
+        f, g = f.copy(), g.copy()
+        moved = np.abs(X[2] - x0[2]).max() > 0        # frame 2: finite at its start, NaN everywhere else
+        if moved:
+            f[2], g[2] = np.nan, np.nan
+        return f, g
+    x, _ = minimize(fg_bad, x0, lr=1e-2, max_iter=10)
+    ref, _ = minimize(fg, x0, lr=1e-2, max_iter=10)
+    keep = [0, 1, 3, 4]
+    assert np.array_equal(x[keep], ref[keep])         # the other frames never notice
+    assert np.isfinite(x[keep]).all()

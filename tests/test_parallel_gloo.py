@@ -19,7 +19,13 @@ def test_shard_bounds_cover_every_frame_once():
             spans = [parallel.shard_bounds(T, G, r) for r in range(G)]
             assert spans[0][0] == 0 and spans[-1][1] == T
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-            assert max(e - s for s, e in spans) == (T + G - 1) // G
+            assert max(e - s for s, e in spans) == parallel.rows_per_rank(T, G) == (T + G - 1) // G
+            # balanced: block sizes differ by at most one, so no rank is empty unless there are more ranks than frames
+            assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+            assert T < G or all(e > s for s, e in spans)
+            keep = parallel.valid_rows(T, G)
+            per = parallel.rows_per_rank(T, G)
+            assert keep.tolist() == [r * per + i for r, (s, e) in enumerate(spans) for i in range(e - s)]
 
 
 def test_single_rank_async_gather_returns_no_work():
