@@ -123,8 +123,8 @@ typedef struct k2b_fit_config {
      * effective weight 200 in that path).  0 = off. */
     float transl_prior_weight;
     /* Debug / test knob: 0 = the launcher picks the launch shape from the batch size (the product setting);
-     * 1, 2, 3 force the split / split-paired / paired shape of the fused kernel (and a single launch), so that
-     * the parity tests can drive every shape with small cases.  Results do not depend on it.  The tree kernel of the larger
+     * 1, 2, 3, 4 force the split / split-paired / paired / wide (16-wave) shape of the fused kernel (and a single launch), so
+     * that the parity tests can drive every shape with small cases.  Results do not depend on it.  The tree kernel of the larger
      * models has two shapes: 1 = plain (every wave a frame + its share of the mixture), 2 = four extra component waves. */
     int32_t debug_launch_shape;
     /* Larger models (SMPL-H / SMPL-X): `body_pose` holds ALL non-root joints (SMPL-X: body 63 | jaw, eyes 9 | hands

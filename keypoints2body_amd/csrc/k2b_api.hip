@@ -745,8 +745,8 @@ int fit_tree(k2b_model* model, k2b_prior* prior, const k2b_fit_config* cfg, int 
     a.opt_mask = cfg->optimize_mask & 15;
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;
-    if (cfg->debug_launch_shape < 0 || cfg->debug_launch_shape > 3)
-        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: debug_launch_shape=%d must be 0..3", cfg->debug_launch_shape);
+    if (cfg->debug_launch_shape < 0 || cfg->debug_launch_shape > 4)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: debug_launch_shape=%d must be 0..4", cfg->debug_launch_shape);
     a.debug_shape = cfg->debug_launch_shape <= 2 ? cfg->debug_launch_shape : 0;   // tree kernel: 1 = plain, 2 = component waves
     if (!vsel.empty()) {
         if (num_kinematic == 0)
@@ -932,8 +932,8 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     a.freeze_betas = cfg->freeze_betas ? 1 : 0;
     a.opt_mask = (cfg->optimize_mask & 15) & (cfg->freeze_betas ? ~4 : ~0);
     a.transl_prior_w = cfg->transl_prior_weight;
-    if (cfg->debug_launch_shape < 0 || cfg->debug_launch_shape > 3)
-        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: debug_launch_shape=%d must be 0..3", cfg->debug_launch_shape);
+    if (cfg->debug_launch_shape < 0 || cfg->debug_launch_shape > 4)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: debug_launch_shape=%d must be 0..4", cfg->debug_launch_shape);
     a.force_shape = cfg->debug_launch_shape;
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;

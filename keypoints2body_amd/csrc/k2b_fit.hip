@@ -86,7 +86,8 @@ constexpr int YX_STRIDE = MG * NC + 4;  // y exchange: [slot][m][64] (+4: b128 s
 constexpr int DD_STRIDE_MAX = 52;        // per-lane stride of the J_dirs table in LDS (see the kernel)
 constexpr int PLO_FLOATS = MG * 4 * 2 * 64 * 4;   // lo fragments of all components (paired shape): [m][tile][ks][64 lanes][8 halfs]
 constexpr int WX_FLOATS = MAXS * 64;                 // rim rows' products: [slot][lane 8 m + s] = (P_m[64 + s][0..63] theta)[s < 5], zeros for s >= 5
-constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + RF_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX + PLO_FLOATS + WX_FLOATS;
+constexpr int RC_FLOATS = 8 * 64;                    // per-lane rim constants (FitArgs::row_const) for the 16-wave shapes, which have no registers for them
+constexpr int LDS_FLOATS = RIM_FLOATS + CMU_FLOATS + RF_FLOATS + MAXS * SLOT + MAXS * MG + MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX + PLO_FLOATS + WX_FLOATS + RC_FLOATS;
 static_assert(LDS_FLOATS * 4 <= 163840, "LDS budget");
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -169,18 +170,50 @@ __device__ __forceinline__ float butterfly16_half_sum(const float (&v)[16], int 
 
 }  // namespace
 
-enum { MODE_SPLIT = 0, MODE_SPLIT_PAIRED = 1, MODE_PAIRED = 2 };
+// Round 4: a fourth shape with SIXTEEN waves per workgroup for 9..16 frames per CU (the 4096-frame headline).  A wave on its own
+// issues a vector instruction every ~4.5 cycles while its SIMD can take one every ~2.5 from several (MI355X_MICROARCH.md,
+// "vector-instruction ISSUE cost"; tools/probe/pk_rate.hip), and every role of this kernel is a dependent chain with LDS round
+// trips and cross-lane moves: the `paired` shape's two waves per SIMD left the vector pipe half idle.
+//   wide   <= 16 frames per CU: eight ROW waves (one mixture component + the optimiser state of two frames each) and eight TREE
+//          waves (two frames each, one tree per 32-lane half) - four waves per SIMD, at most 128 registers per lane.  The row
+//          role has its own lean code path below (set B of both frames packed into one register set, lo / rim fragments streamed
+//          from LDS tile by tile, a tile consumed under the next tile's products); the tree role is the split-paired one with
+//          its J_dirs table in LDS.  4096 frames: 0.457 -> 0.38-0.40 ms.
+// (Measured and NOT kept in round 4: `split` with eight row waves of one component each (12 waves: the row waves' component
+//  chain is halved but runs in the tree wave's shadow either way - 0.2465 against 0.2428 ms at 1024 frames), and a 16-wave shape
+//  with one frame per wave (twice the tree instructions per frame: 0.399 against 0.294 ms at 2048 frames).)
+enum { MODE_SPLIT = 0, MODE_SPLIT_PAIRED = 1, MODE_PAIRED = 2, MODE_WIDE = 3 };
+
+template <int MODE> struct Shape {
+    static constexpr bool SPLIT = MODE != MODE_PAIRED;
+    static constexpr bool PAIR = MODE != MODE_SPLIT;
+    static constexpr int NROW = MODE == MODE_WIDE ? 8 : 4;                                   // row waves (split shapes)
+    static constexpr int NWAVES = SPLIT ? 2 * NROW : MAXW;                                   // as many tree waves as row waves
+    static constexpr int CPW = MG / NROW;                                                    // mixture components per row wave
+};
+
+// torch.optim.Adam, single-tensor path, for one parameter; the fused operations are pinned so that every code path of the
+// kernel rounds alike whatever the compiler would contract in its context (co = {lr / (1 - b1^t), sqrt(1 - b2^t)})
+__device__ __forceinline__ void adam_update(float& x, float& m, float& v, float g, float2 co, float inv_bc2, float om_b1, float beta2,
+                                            float om_b2, float eps) {
+    m = __builtin_fmaf(om_b1, g - m, m);
+    v = __builtin_fmaf(om_b2 * g, g, v * beta2);
+    const float denom = __builtin_fmaf(fast_sqrt(v), inv_bc2, eps);
+    x = __builtin_fmaf(-co.x, m * fast_rcp(denom), x);
+}
 
 template <int NBT, int MODE>
-__global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs a) {
-    constexpr bool SPLIT = MODE == MODE_SPLIT || MODE == MODE_SPLIT_PAIRED, PAIR = MODE == MODE_PAIRED || MODE == MODE_SPLIT_PAIRED;
+__global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel(const FitArgs a) {
+    constexpr bool SPLIT = Shape<MODE>::SPLIT, PAIR = Shape<MODE>::PAIR;
+    constexpr int NROW = Shape<MODE>::NROW, CPW = Shape<MODE>::CPW;
+    constexpr bool WIDE16 = Shape<MODE>::NWAVES == 16;       // four waves per SIMD: 128 registers per lane
     constexpr int FW = PAIR ? 2 : 1;         // frames a wave carries in its row and tree roles
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ int row_sync_cell;                    // split shape: meeting point of the four row waves
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;               // always 8 waves: wave w also owns mixture component w
+    const int wave = tid >> 6;               // 8, 12 or 16 waves by shape
     const int M = a.num_gauss;
     const int F = a.frames_per_wg;           // frame slots of this workgroup (split <= 4, split-paired <= 8, paired <= 16)
     int* row_sync = &row_sync_cell;
@@ -201,10 +234,10 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     //            both roles for its two slots.
     // (split shape with one or two frames: the tree wave of slot s is wave 4 + ((s + 2) & 3), i.e. it sits on the SIMD of an idle
     //  row slot instead of sharing its own row wave's SIMD - the two roles of a frame are co-critical and issue-bound together)
-    const bool spread = SPLIT && !PAIR && F <= 2 && wave >= 4;
-    const int slot0 = (PAIR ? 2 : 1) * (SPLIT ? (spread ? ((wave + 2) & 3) : (wave & 3)) : wave);
-    const bool do_row = slot0 < F && (!SPLIT || wave < 4);     // rim of the prior, priors in row layout, Adam, results
-    const bool do_tree = slot0 < F && (!SPLIT || wave >= 4);   // kinematics, joint loss, analytic backward
+    const bool spread = MODE == MODE_SPLIT && F <= 2 && wave >= 4;
+    const int slot0 = (PAIR ? 2 : 1) * (SPLIT ? (spread ? ((wave + 2) & 3) : (wave < NROW ? wave : wave - NROW)) : wave);
+    const bool do_row = slot0 < F && (!SPLIT || wave < NROW);     // rim of the prior, priors in row layout, Adam, results
+    const bool do_tree = slot0 < F && (!SPLIT || wave >= NROW);   // kinematics, joint loss, analytic backward
     // every wave must reach every barrier: a padding slot recomputes the last frame and skips the final stores
     int f[FW];
     bool f_valid[FW];
@@ -227,7 +260,12 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     float* ddl = yx + MAXS * YX_STRIDE;
     half8* plo = reinterpret_cast<half8*>(ddl + 64 * DD_STRIDE_MAX);   // paired shape: lo fragments, [m][tile][ks][lane]
     float* wx = reinterpret_cast<float*>(plo) + PLO_FLOATS;           // [slot][64]
-    if (PAIR && !SPLIT) {
+    float* rcl = wx + WX_FLOATS;                                      // [8][64]: row_const (16-wave shapes)
+    constexpr bool RC_IN_LDS = WIDE16;
+    if (RC_IN_LDS)
+        for (int i = tid; i < RC_FLOATS; i += blockDim.x) rcl[i] = a.row_const[i];
+    constexpr bool DD_IN_LDS = (PAIR && !SPLIT) || WIDE16;
+    if (DD_IN_LDS) {
         for (int i = tid; i < 64 * DDN; i += blockDim.x) {
             const int l = i / DDN, r = i % DDN;
             ddl[l * DD_STRIDE + r] = a.dd[(l * 3 + r / NBT) * kMaxBetas + r % NBT];
@@ -265,12 +303,14 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // rim of the prior: lane (gm = l >> 3, gs = l & 7) works on component gm, columns 8 gs .. 8 gs + 7;
     // lanes gs < 5 finish rim row 64 + gs of that component
     const int gm = lane >> 3, gs = lane & 7;
-    float pbb[NR];
+    float pbb_r[NR], cB_r = 0.f, kB_r = 0.f, muB_r = 0.f;
+    if (!RC_IN_LDS) {
 #pragma unroll
-    for (int k = 0; k < NR; ++k) pbb[k] = a.row_const[k * 64 + lane];     // P_gm[64 + gs][64 + k]
-    const float cB = a.row_const[5 * 64 + lane];    // (P mu)[64 + gs]
-    const float kB = a.row_const[6 * 64 + lane];    // (P_BA mu_A)[gs]
-    const float muB = a.row_const[7 * 64 + lane];   // mu[64 + gs]
+        for (int k = 0; k < NR; ++k) pbb_r[k] = a.row_const[k * 64 + lane];     // P_gm[64 + gs][64 + k]
+        cB_r = a.row_const[5 * 64 + lane];    // (P mu)[64 + gs]
+        kB_r = a.row_const[6 * 64 + lane];    // (P_BA mu_A)[gs]
+        muB_r = a.row_const[7 * 64 + lane];   // mu[64 + gs]
+    }
     // float4 index of P_m[64 + c][lane] (= P_m[lane][64 + c]) in the rim image, without the m and c terms
     const int rimcol = (((lane >> 2) & 1) * 64 + (lane >> 3)) * 4 + (lane & 3);
 
@@ -311,7 +351,7 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // J_dirs differences of this lane: registers in the split shapes (the LDS reads would sit on
     // the tree's critical path), LDS in the paired shape (two frames of optimiser state per wave leave no
     // room for 30-48 more loop-invariant registers)
-    constexpr bool DD_IN_LDS = PAIR && !SPLIT;
+    // (the 16-wave shapes have 128 registers per lane: LDS there too)
     float ddr[DD_IN_LDS ? 1 : 4 * DDQ];
     if (!DD_IN_LDS) {
 #pragma unroll
@@ -411,6 +451,44 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     //  next to two frames of optimiser state)
     auto comp_issue = [&](const half8 (&ph)[4][2], const half8 (&plr)[4][2], floatx4 (&yacc)[5], int lds_comp, int comp) __attribute__((always_inline)) {
         // lds_comp >= 0: the lo fragments of that component are read from LDS instead of registers
+        if constexpr (WIDE16) {
+            // 128 registers per lane: the lo fragments of a tile are requested one tile ahead (8 registers in flight instead of 32),
+            // the rim fragments behind the third tile; tile-major, every tile's own chain in the usual order (bit-identical)
+            const half8* plc = plo + (size_t)lds_comp * 4 * 2 * 64 + lane;
+            const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
+            const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
+            const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
+            const half8 bl1 = *reinterpret_cast<const half8*>(cth_lo + 32 + 8 * cg);
+            const half8* rf = rimfrag + comp * kPriorRimFragEntries + ridx;
+            half8 nl0 = plc[0], nl1 = plc[64];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const half8 l0 = nl0, l1 = nl1;
+                if (t < 3) { nl0 = plc[((t + 1) * 2) * 64]; nl1 = plc[((t + 1) * 2 + 1) * 64]; }
+                else { nl0 = rf[21]; nl1 = rf[63]; }                       // rl0, rl1
+                __builtin_amdgcn_sched_barrier(0);
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, bh0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, bh1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bl0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bl1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bh0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bh1, acc, 0, 0, 0);
+                yacc[t] = acc;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const half8 rh0 = rf[0], rh1 = rf[42];
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(nl0, bh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(nl1, bh1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bl0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bl1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bh1, acc, 0, 0, 0);
+            yacc[4] = acc;
+            asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+            return;
+        }
         half8 pl[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -663,6 +741,12 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             const float t68 = xs[XS_BODY + NC + 4];
             float yBv, qrim;
             {
+                float pbb[NR], cB, kB, muB;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) pbb[k] = RC_IN_LDS ? rcl[k * 64 + lane] : pbb_r[k];
+                cB = RC_IN_LDS ? rcl[5 * 64 + lane] : cB_r;
+                kB = RC_IN_LDS ? rcl[6 * 64 + lane] : kB_r;
+                muB = RC_IN_LDS ? rcl[7 * 64 + lane] : muB_r;
                 const float wm = wx[slot * 64 + lane], tB = xs[tBoff];
                 const float vB = pbb[0] * t64.x + pbb[1] * t64.y + pbb[2] * t64.z + pbb[3] * t64.w + pbb[4] * t68;
                 const float y = wm + vB - cB;
@@ -711,18 +795,8 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         // torch.optim.Adam, single-tensor path
         const float2 co = a.adam_coef[it];     // {lr / (1 - b1^t), sqrt(1 - b2^t)}
         const float inv_bc2 = fast_rcp(co.y);
-        {
-            m0[h] = m0[h] + om_b1 * (g0[h] - m0[h]);
-            v0[h] = v0[h] * a.beta2 + om_b2 * g0[h] * g0[h];
-            const float denom = fast_sqrt(v0[h]) * inv_bc2 + a.eps;
-            x0[h] = x0[h] - co.x * (m0[h] * fast_rcp(denom));
-        }
-        {
-            m1[h] = m1[h] + om_b1 * (g1[h] - m1[h]);
-            v1[h] = v1[h] * a.beta2 + om_b2 * g1[h] * g1[h];
-            const float denom = fast_sqrt(v1[h]) * inv_bc2 + a.eps;
-            x1[h] = x1[h] - co.x * (m1[h] * fast_rcp(denom));
-        }
+        adam_update(x0[h], m0[h], v0[h], g0[h], co, inv_bc2, om_b1, a.beta2, om_b2, a.eps);
+        adam_update(x1[h], m1[h], v1[h], g1[h], co, inv_bc2, om_b1, a.beta2, om_b2, a.eps);
         }  // frames of this wave
     };
 
@@ -740,10 +814,12 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
     // Two workgroup barriers per iteration in every role: [parameters published] and [gradients, y, q
     // published].  The roles of the split shape run their own loops, so that the tree waves carry no
     // component registers and the row waves no tree registers.
-    if (SPLIT && wave >= 4) {
+    if (SPLIT && wave >= NROW) {
         // tree waves: kinematics, joint loss, analytic backward.  They are the iteration's critical path and share their SIMD
         // with a row wave: raised priority, so that the row wave (and its MFMAs, which hold the SIMD for 16 cycles each) fills
         // the tree wave's stalls instead of competing for its issue slots
+        // (wide shape, same-box A/B at 4096 frames: tree waves 3 / row waves 0 0.3815 ms; rows above trees 0.417; all equal 0.417 -
+        //  the row waves issue few instructions and are starved either way, the tree waves are what the SIMD must keep fed)
         __builtin_amdgcn_s_setprio(3);
         const int steps = PAIR ? 1 : a.chain_len;
         for (int step = 0; step < steps; ++step) {
@@ -769,19 +845,240 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
         }
         return;
     }
+    if constexpr (MODE == MODE_WIDE) {
+        // ---- row waves of the 16-wave shape: component `wave`, optimiser state of slots 2 wave and 2 wave + 1 -------------------
+        // 128 registers per lane (four waves per SIMD), so this path is written for short live ranges instead of sharing the
+        // lambdas above: set B of BOTH frames is packed into one register set (frame h in lanes 32 h + k: 19 of 32 lanes used
+        // instead of 19 of 64 twice - one Adam update, one publish), the lo fragments and the rim fragments stream from LDS one
+        // tile at a time, and a tile is consumed while the next one's products run.  Every value is computed by the same
+        // operations in the same order as in the other shapes: results are bit-identical.
+        const int hq = lane >> 5, kq = lane & 31;                      // packed set B: frame slot0 + hq, parameter kq
+        const bool actQ = kq < nparamB, bodyQ = kq < NR, goQ = kq >= NR && kq < 8, betaQ = kq >= 8 && kq < 8 + NB;
+        const bool translQ = actQ && !bodyQ && !goQ && !betaQ;
+        const int offQ = bodyQ ? XS_BODY + NC + kq : (goQ ? kq - NR : (betaQ ? XS_BETA + (kq - 8) : XS_TRANSL + (kq - 8 - NB)));
+        const int pQ = bodyQ ? 3 + NC + kq : (goQ ? kq - NR : (betaQ ? 3 + D + (kq - 8) : 3 + D + NB + (kq - 8 - NB)));
+        const bool optQ = actQ && ((a.opt_mask >> (bodyQ ? 1 : (goQ ? 0 : (betaQ ? 2 : 3)))) & 1);
+        const int fQ = hq ? f[1] : f[0];
+        const bool validQ = hq ? f_valid[1] : f_valid[0];
+        float xa[2], ma[2], va[2], pra[2];                             // set A of the two frames
+        float xq, mq = 0.f, vq = 0.f, refQ;                            // set B, packed
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xa[h] = a.bp_in[(size_t)f[h] * D + lane];
+            pra[h] = prsrc[(size_t)f[h] * D + lane];
+            ma[h] = va[h] = 0.f;
+        }
+        xq = actQ ? *param_ptr(fQ, pQ, a.go_in, a.bp_in, a.be_in, a.tr_in) : 0.f;
+        refQ = bodyQ ? prsrc[(size_t)fQ * D + NC + kq] : (translQ ? a.tr_prior[(size_t)fQ * 3 + (kq - 8 - NB)] : 0.f);
+        const float cyQ = bodyQ ? wpp2 : 0.f;
+        const float cqQ = bodyQ ? wpr2 : (betaQ ? ws2 : (translQ ? wt2 : 0.f));
+        float* const xsQ = slots + (slot0 + hq) * SLOT;                // this lane's set-B strips
+        const bool rowQ = slot0 + hq < F;                              // (a workgroup's last wave may carry one frame only)
+        half8 ph[4][2];
+        {
+            half8 plq[4][2];
+            load_frags(wave, ph, plq);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) plo[((wave * 4 + t) * 2 + ks) * 64 + lane] = plq[t][ks];
+        }
+        const half8* const plc = plo + (size_t)wave * 4 * 2 * 64 + lane;
+        const half8* const rf = rimfrag + wave * kPriorRimFragEntries + ridx;
+        const float inv_scale = a.inv_scale[wave];
+        const float* const cmu_c = cmu + wave * 2 * NC + 4 * cg;
+        float g0o[2] = {0.f, 0.f}, gqo = 0.f, losso[2] = {0.f, 0.f};
+        K2B_FSTAMP_DECL;
+        for (int it = 0; it < a.num_iters; ++it) {
+            const bool last = it == a.num_iters - 1;
+            const float2 co = a.adam_coef[it];         // requested a whole iteration ahead of its use (behind barrier 2 it was a
+                                                       // global load with a full wait on the iteration's critical path)
+            K2B_FSTAMP(0);
+            // ---- publish -------------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (slot0 + h < F) {
+                    float* xs = slots + (slot0 + h) * SLOT;
+                    xs[offA] = xa[h];
+                    if (use_gmm) {
+                        _Float16* th_hi = reinterpret_cast<_Float16*>(xs + 2 * XS);
+                        const _Float16 hh = (_Float16)xa[h];
+                        th_hi[lane] = hh;
+                        th_hi[NC + lane] = (_Float16)(xa[h] - (float)hh);
+                    }
+                }
+            }
+            if (actQ && rowQ) xsQ[offQ] = xq;
+            K2B_FSTAMP(1);
+            __syncthreads();
+            K2B_FSTAMP(2);
+            // ---- component `wave` for all 16 slots: products tile by tile, tile t - 1 consumed under the products of tile t ----
+            if (use_gmm) {
+                const half8 bh0 = *reinterpret_cast<const half8*>(cth_hi + 8 * cg);
+                const half8 bh1 = *reinterpret_cast<const half8*>(cth_hi + 32 + 8 * cg);
+                const half8 bl0 = *reinterpret_cast<const half8*>(cth_lo + 8 * cg);
+                const half8 bl1 = *reinterpret_cast<const half8*>(cth_lo + 32 + 8 * cg);
+                float qp = 0.f;
+                floatx4 accp = {0.f, 0.f, 0.f, 0.f};
+                auto consume_tile = [&](int t, const floatx4& acc) __attribute__((always_inline)) {
+                    const float4 th4 = *reinterpret_cast<const float4*>(cxs + XS_BODY + 16 * t + 4 * cg);
+                    const float4 mu4 = *reinterpret_cast<const float4*>(cmu_c + 16 * t);
+                    const float4 c4 = *reinterpret_cast<const float4*>(cmu_c + NC + 16 * t);
+                    float4 y;
+                    y.x = acc[0] * inv_scale - c4.x;
+                    y.y = acc[1] * inv_scale - c4.y;
+                    y.z = acc[2] * inv_scale - c4.z;
+                    y.w = acc[3] * inv_scale - c4.w;
+                    qp += (th4.x - mu4.x) * y.x + (th4.y - mu4.y) * y.y + (th4.z - mu4.z) * y.z + (th4.w - mu4.w) * y.w;
+                    *reinterpret_cast<float4*>(yx + cslot * YX_STRIDE + wave * NC + 16 * t + 4 * cg) = y;
+                };
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const half8 l0 = plc[(2 * t) * 64], l1 = plc[(2 * t + 1) * 64];
+                    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, bh1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bl0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bl1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][0], bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[t][1], bh1, acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t > 0) consume_tile(t - 1, accp);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accp = acc;
+                }
+                {
+                    const half8 rh0 = rf[0], rl0 = rf[21], rh1 = rf[42], rl1 = rf[63];
+                    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl0, bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl1, bh1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bl0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bl1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh0, bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh1, bh1, acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume_tile(3, accp);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" ::"v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+                    qp = pair_sum32(qp);
+                    qp = pair_sum16(qp);
+                    qx[cslot * MG + wave] = qp;
+                    if (cg < 2) {
+                        float4 w;
+                        w.x = acc[0] * inv_scale; w.y = acc[1] * inv_scale; w.z = acc[2] * inv_scale; w.w = acc[3] * inv_scale;
+                        *reinterpret_cast<float4*>(wx + cslot * 64 + wave * 8 + 4 * cg) = w;
+                    }
+                }
+                K2B_FSTAMP(3);
+                K2B_FSTAMP(4);
+                if (lane == 0) __hip_atomic_fetch_add(row_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int target = NROW * (it + 1);
+                while (__hip_atomic_load(row_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+            }
+            K2B_FSTAMP(5);
+            // ---- priors: per frame in the (component, rim row) lane layout, then the set-A gradient; set B once for both --------
+            float gpa[2] = {0.f, 0.f}, lossp[2] = {0.f, 0.f}, bestv[2] = {0.f, 0.f};
+            float yQ = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (slot0 + h >= F) continue;
+                const int slot = slot0 + h;
+                const float* xs = slots + slot * SLOT;
+                float yA = 0.f, best = 0.f;
+                if (use_gmm) {
+                    const float4 t64 = *reinterpret_cast<const float4*>(xs + XS_BODY + NC);
+                    const float t68 = xs[XS_BODY + NC + 4];
+                    float yBv, qrim;
+                    {
+                        const float wm = wx[slot * 64 + lane], tB = xs[tBoff];
+                        const float vB = rcl[0 * 64 + lane] * t64.x + rcl[1 * 64 + lane] * t64.y + rcl[2 * 64 + lane] * t64.z + rcl[3 * 64 + lane] * t64.w + rcl[4 * 64 + lane] * t68;
+                        const float y = wm + vB - rcl[5 * 64 + lane];
+                        const float term = tB * (wm - rcl[6 * 64 + lane]) + (tB - rcl[7 * 64 + lane]) * y;
+                        yBv = gs < NR ? y : 0.f;
+                        qrim = group8_sum(gs < NR ? term : 0.f);
+                    }
+                    const float q = qrim + qx[slot * MG + gm];
+                    float val = 0.5f * q + a.neg_log_nllw[gm < M ? gm : 0];
+                    val = gm < M ? val : __builtin_inff();
+                    best = group8_wave_min(val);
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(val == best);
+                    const int mstar = hit ? (int)(__builtin_ctzll(hit) >> 3) : 0;
+                    yA = yx[slot * YX_STRIDE + mstar * NC + lane];
+                    const float* rimf = lds + mstar * 32 + rimcol;
+                    yA += rimf[0 * 512] * t64.x + rimf[1 * 512] * t64.y + rimf[2 * 512] * t64.z + rimf[3 * 512] * t64.w + rimf[4 * 512] * t68;
+                    const float yb = bperm((8 * mstar + (kq < NR ? kq : 0)) * 4, yBv);      // rows 64 + kq, for both halves
+                    yQ = hq == h ? yb : yQ;
+                }
+                const float dA = xa[h] - pra[h];
+                const float eA = __expf(xa[h] * angA);
+                gpa[h] = wpp2 * yA + 2.f * wpr2 * dA + (wa2 * 2.f * angA) * (eA * eA);
+                if (last) lossp[h] = wpr2 * dA * dA + (angA != 0.f ? wa2 * eA * eA : 0.f);
+                bestv[h] = best;
+            }
+            const float dQ = xq - refQ;
+            const float gpq = cyQ * yQ + 2.f * cqQ * dQ;
+            if (last) {
+                // the set-B share of a frame's prior loss joins the partial of the lane it sits on in the other shapes (lane kq)
+                float pq0 = cqQ * dQ * dQ, pq1 = pq0;
+                swap32(pq0, pq1);                      // pq1: lanes kq < 32 receive the value of lane 32 + kq (frame 1)
+                lossp[0] += hq == 0 ? cqQ * dQ * dQ : 0.f;
+                lossp[1] += hq == 0 ? pq1 : 0.f;
+            }
+            K2B_FSTAMP(6);
+            __syncthreads();
+            K2B_FSTAMP(7);
+            // ---- joint gradient from the tree waves, Adam ------------------------------------------------------------------------
+            const float inv_bc2 = fast_rcp(co.y);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (slot0 + h >= F) continue;
+                const float* gs_r = slots + (slot0 + h) * SLOT + XS;
+                const float g = optA ? gs_r[offA] + gpa[h] : 0.f;
+                if (last) { g0o[h] = g; losso[h] = wave_sum_fast(lossp[h]) + wpp2 * bestv[h] + gs_r[XS - 1]; }
+                adam_update(xa[h], ma[h], va[h], g, co, inv_bc2, om_b1, a.beta2, om_b2, a.eps);
+            }
+            {
+                const float g = (optQ && rowQ) ? xsQ[XS + offQ] + gpq : 0.f;
+                if (last) gqo = g;
+                adam_update(xq, mq, vq, g, co, inv_bc2, om_b1, a.beta2, om_b2, a.eps);
+            }
+            K2B_FSTAMP(8);
+        }
+        K2B_FSTAMP_ROW_PRINT;
+        // ---- results -------------------------------------------------------------------------------------------------------------
+        const int P = 3 + D + NB + 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!f_valid[h]) continue;
+            a.bp_out[(size_t)f[h] * D + lane] = xa[h];
+            if (lane == 0 && a.loss_out) a.loss_out[f[h]] = losso[h];
+            if (a.grad_out) a.grad_out[(size_t)f[h] * P + pA] = g0o[h];
+        }
+        if (actQ && validQ) {
+            float* dst = pQ < 3 ? a.go_out + (size_t)fQ * 3 + pQ
+                       : (pQ < 3 + D ? a.bp_out + (size_t)fQ * D + (pQ - 3)
+                       : (pQ < 3 + D + NB ? a.be_out + (size_t)fQ * NB + (pQ - 3 - D) : a.tr_out + (size_t)fQ * 3 + (pQ - 3 - D - NB)));
+            *dst = xq;
+            if (a.grad_out) a.grad_out[(size_t)fQ * P + pQ] = gqo;
+        }
+        return;
+    }
     if (SPLIT) {
         // row waves: optimiser state of slot `wave`, mixture components `wave` and `wave + 4`
         // (the lo fragments of the second component are parked in LDS: 96 instead of 128 resident registers,
         //  which keeps this loop free of scratch spills)
-        half8 pa_h[4][2], pa_l[4][2], pb_h[4][2], pb_l[4][2];
+        //  With eight row waves (round 4) a row wave carries ONE component: both halves in registers at 12 waves per CU (168
+        //  registers), the lo half in LDS at 16 (128).
+        constexpr bool LO_A_IN_LDS = PAIR || CPW == 1;
+        half8 pa_h[4][2], pa_l[4][2], pb_h[CPW == 2 ? 4 : 1][2], pb_l[CPW == 2 ? 4 : 1][2];
         load_frags(wave, pa_h, pa_l);
-        load_frags(wave + 4, pb_h, pb_l);
+        if constexpr (CPW == 2) load_frags(wave + 4, pb_h, pb_l);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                plo[(((wave + 4) * 4 + t) * 2 + ks) * 64 + lane] = pb_l[t][ks];
-                if (PAIR) plo[((wave * 4 + t) * 2 + ks) * 64 + lane] = pa_l[t][ks];   // two frames of optimiser state: both
+                if constexpr (CPW == 2) plo[(((wave + 4) * 4 + t) * 2 + ks) * 64 + lane] = pb_l[t][ks];
+                if (LO_A_IN_LDS) plo[((wave * 4 + t) * 2 + ks) * 64 + lane] = pa_l[t][ks];   // two frames of optimiser state: both
             }
         auto out_ptr_c = [&](size_t fr, int p) -> float* {
             if (p < 3) return a.go_out + fr * 3 + p;
@@ -810,20 +1107,20 @@ __global__ __launch_bounds__(MAXW * 64) void k2b_fit_world_kernel(const FitArgs 
             K2B_FSTAMP(2);
             floatx4 ya[5], yb[5];
             if (use_gmm) {
-                comp_issue(pa_h, pa_l, ya, PAIR ? wave : -1, wave);
-                comp_issue(pb_h, pb_l, yb, wave + 4, wave + 4);
+                comp_issue(pa_h, pa_l, ya, LO_A_IN_LDS ? wave : -1, wave);
+                if constexpr (CPW == 2) comp_issue(pb_h, pb_l, yb, wave + 4, wave + 4);
             }
             K2B_FSTAMP(3);
             if (use_gmm) {
                 comp_consume(ya, wave);
-                comp_consume(yb, wave + 4);
+                if constexpr (CPW == 2) comp_consume(yb, wave + 4);
                 // the four row waves hold all eight components between them: they meet at an LDS counter
                 // (release after their y / q writes, acquire before reading the others') so that the
                 // arg-min and the priors' gradient are done while the tree waves still work, and only
                 // "add the joint gradient, Adam, publish" is left on the iteration's critical path
                 K2B_FSTAMP(4);
                 if (lane == 0) __hip_atomic_fetch_add(row_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int target = 4 * (git + 1);
+                const int target = NROW * (git + 1);
                 while (__hip_atomic_load(row_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
             K2B_FSTAMP(5);
@@ -939,28 +1236,29 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     // (SIMDs would idle, so every frame gets two cooperating waves); up to 8: one wave per frame;
     // beyond: two frames per wave.
     int fpw = (a.num_frames + a.num_cus - 1) / a.num_cus;
-    int mode = fpw <= 4 ? MODE_SPLIT : (fpw <= MAXW ? MODE_SPLIT_PAIRED : MODE_PAIRED);
+    int mode = fpw <= 4 ? MODE_SPLIT : (fpw <= MAXW ? MODE_SPLIT_PAIRED : MODE_WIDE);
     // k2b_fit_config::debug_launch_shape forces a shape regardless of the batch size, so that the parity tests can
-    // drive every shape with the small golden cases
+    // drive every shape with the small golden cases (1..3: the 8-wave shapes of rounds 1-3; 4: the 16-wave one)
+    static const int forced[5] = {0, MODE_SPLIT, MODE_SPLIT_PAIRED, MODE_PAIRED, MODE_WIDE};
+    auto cap_of = [](int m) { return m == MODE_SPLIT ? 4 : ((m == MODE_PAIRED || m == MODE_WIDE) ? MAXS : MAXW); };
     if (a.force_shape) {
-        mode = a.force_shape == 1 ? MODE_SPLIT : (a.force_shape == 2 ? MODE_SPLIT_PAIRED : MODE_PAIRED);
-        fpw = mode == MODE_SPLIT ? 4 : (mode == MODE_PAIRED ? MAXS : MAXW);
-        if (fpw > a.num_frames) fpw = a.num_frames;
+        mode = forced[a.force_shape];
+        // small (test) batches fill the shape's slots; batches of a CU count or more keep one workgroup per CU where the shape can
+        if (a.num_frames < a.num_cus) { fpw = cap_of(mode); if (fpw > a.num_frames) fpw = a.num_frames; }
     }
-    const int cap = mode == MODE_SPLIT ? 4 : (mode == MODE_PAIRED ? MAXS : MAXW);
+    const int cap = cap_of(mode);
     fpw = fpw < 1 ? 1 : (fpw > cap ? cap : fpw);
     a.frames_per_wg = fpw;
-    const dim3 grid((a.num_frames + fpw - 1) / fpw), block(MAXW * 64);   // always 8 waves: wave w carries mixture component w
-#define K2B_LAUNCH(NBT_, MODE_) hipLaunchKernelGGL((k2b_fit_world_kernel<NBT_, MODE_>), grid, block, 0, stream, a)
-    if (a.num_betas <= 10) {
-        if (mode == MODE_SPLIT) K2B_LAUNCH(10, MODE_SPLIT);
-        else if (mode == MODE_SPLIT_PAIRED) K2B_LAUNCH(10, MODE_SPLIT_PAIRED);
-        else K2B_LAUNCH(10, MODE_PAIRED);
-    } else {
-        if (mode == MODE_SPLIT) K2B_LAUNCH(16, MODE_SPLIT);
-        else if (mode == MODE_SPLIT_PAIRED) K2B_LAUNCH(16, MODE_SPLIT_PAIRED);
-        else K2B_LAUNCH(16, MODE_PAIRED);
+    const dim3 grid((a.num_frames + fpw - 1) / fpw);
+#define K2B_LAUNCH(NBT_, MODE_) hipLaunchKernelGGL((k2b_fit_world_kernel<NBT_, MODE_>), grid, dim3(Shape<MODE_>::NWAVES * 64), 0, stream, a)
+#define K2B_LAUNCH_NB(MODE_) do { if (a.num_betas <= 10) K2B_LAUNCH(10, MODE_); else K2B_LAUNCH(16, MODE_); } while (0)
+    switch (mode) {
+        case MODE_SPLIT: K2B_LAUNCH_NB(MODE_SPLIT); break;
+        case MODE_SPLIT_PAIRED: K2B_LAUNCH_NB(MODE_SPLIT_PAIRED); break;
+        case MODE_PAIRED: K2B_LAUNCH_NB(MODE_PAIRED); break;
+        default: K2B_LAUNCH_NB(MODE_WIDE); break;
     }
+#undef K2B_LAUNCH_NB
 #undef K2B_LAUNCH
     return hipGetLastError();
 }

@@ -63,7 +63,7 @@ struct FitArgs {
     float angle_sign[4];
     int num_cus;
     int chain_len, chain_iters; // warm-start chain: num_frames SEQUENCES of chain_len frames each (1: independent frames)
-    int force_shape;            // 0 = chosen by the batch size; 1..3 = split / split-paired / paired (k2b_fit_config::debug_launch_shape)
+    int force_shape;            // 0 = chosen by the batch size; 1..4 = split / split-paired / paired / wide (k2b_fit_config::debug_launch_shape)
 };
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);

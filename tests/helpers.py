@@ -121,7 +121,7 @@ def cuda(x):
     return torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda().contiguous()
 
 
-LAUNCH_SHAPES = {"auto": 0, "split": 1, "split_paired": 2, "paired": 3}     # k2b_fit_config.debug_launch_shape
+LAUNCH_SHAPES = {"auto": 0, "split": 1, "split_paired": 2, "paired": 3, "wide": 4}     # k2b_fit_config.debug_launch_shape
 
 
 def native_fit(d, num_iters=None, want_grad=False, rows=None, shape="auto"):

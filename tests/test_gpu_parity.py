@@ -145,10 +145,10 @@ def test_fit_matches_reference_golden(case):
     print(f"{case}: worst parameter deviation over the trace = {worst:.2e}")
 
 
-@pytest.mark.parametrize("shape", ["split", "split_paired", "paired"])
+@pytest.mark.parametrize("shape", ["split", "split_paired", "paired", "wide"])
 def test_every_launch_shape_matches_reference_golden(shape):
-    """The fit kernel has three launch shapes chosen by frames per CU (row + tree wave per frame, row + tree
-    wave per two frames, one wave for two frames).  `k2b_fit_config.debug_launch_shape` forces a shape so that each one is pinned to the reference
+    """The fit kernel has four launch shapes (row + tree wave per frame, row + tree wave per two frames, one wave for two
+    frames, and the 16-wave shape of round 4: eight row waves with two frames + one component each, eight tree waves).  `k2b_fit_config.debug_launch_shape` forces a shape so that each one is pinned to the reference
     goldens, including a ragged batch that leaves half a paired wave and several MFMA columns empty."""
     for case in ("amass_batched", "amass_followup", "smpl24_zero_init"):
         d = H.load_case(case)
@@ -169,15 +169,15 @@ def test_launch_shapes_agree_bitwise_on_a_ragged_batch():
     j3d = (j[:, :22] + 0.01).contiguous()
     cfg = native.default_fit_config(); cfg.num_iters = 3
     res = {}
-    for shape in ("split", "split_paired", "paired"):
+    for shape in ("split", "split_paired", "paired", "wide"):
         cfg.debug_launch_shape = H.LAUNCH_SHAPES[shape]
         res[shape] = native.fit_world(m, pr, cfg, list(range(22)), j3d, None, go * 0.9, bp * 0.9, be * 0.5, tr, want_grad=True)
-    for shape in ("split_paired", "paired"):
+    for shape in ("split_paired", "paired", "wide"):
         for k in ("global_orient", "body_pose", "betas", "transl", "loss", "grad"):
             assert torch.equal(res["split"][k], res[shape][k]), f"{shape}: {k}"
 
 
-@pytest.mark.parametrize("shape", ["split", "split_paired", "paired"])
+@pytest.mark.parametrize("shape", ["split", "split_paired", "paired", "wide"])
 def test_sixteen_beta_model_matches_oracle(shape):
     """Models with more than 10 betas run the 16-beta instantiation of the fit kernel.  No reference golden
     exists for that size (the reference ships 10-beta SMPL); the oracle restatement - pinned to the reference
@@ -244,7 +244,7 @@ def test_ill_conditioned_prior_matches_oracle():
     np.testing.assert_allclose(out["loss"].cpu().numpy(), ref.loss.numpy(), rtol=2e-4)
 
 
-@pytest.mark.parametrize("shape", [1, 2, 3])
+@pytest.mark.parametrize("shape", [1, 2, 3, 4])
 def test_rim_heavy_prior_matches_oracle_in_every_shape(shape):
     """Rows 64..68 of every precision matrix ride on the matrix cores as a fifth row tile whose f16 fragments share the
     component's power-of-two scale (k2b_api.hip, k2b_fit.hip).  Here the last five pose dimensions are near-linear functions
@@ -413,7 +413,7 @@ def test_random_configurations_match_oracle(seed):
     cases), each case in one of the three launch shapes: parameters within 1e-4, last-iteration loss within 2e-4
     relative."""
     from keypoints2body_amd import native
-    shape = ("split", "split_paired", "paired")[(seed // 3) % 3]
+    shape = ("split", "split_paired", "paired", "wide")[seed % 4]
     from oracle.fit_torch import FitWeights, fit_world_adam, guess_init_transl
     c = _random_configuration(seed)
     oracle = H.oracle_model()

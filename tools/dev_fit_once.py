@@ -1,5 +1,5 @@
 """Launch the fused fit a few times at a given batch (for rocprofv3 --pmc passes and quick timing).
-usage: python3 tools/dev_fit_once.py FRAMES [pose_prior_weight|-] [launches] [lib variant: tools/libk2b_<name>.so]"""
+usage: python3 tools/dev_fit_once.py FRAMES [pose_prior_weight|-] [launches] [lib variant: tools/libk2b_<name>.so | -] [debug_launch_shape]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
@@ -8,7 +8,7 @@ from keypoints2body_amd import native, synthetic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 wpp = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != '-' else None
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and sys.argv[4] != '-':
     from pathlib import Path
     native._LIB_PATH = Path(__file__).resolve().parent / f'libk2b_{sys.argv[4]}.so'
 m, pr = H.native_model(), H.native_prior()
@@ -20,12 +20,13 @@ z = lambda *s: torch.zeros(*s, device='cuda')
 j0, _ = m.lbs(z(B, 3), z(B, 69), z(B, 10), None, want_vertices=False)
 tr0 = (j3d[:, 0] - j0[:, 0]).contiguous()
 cfg = native.default_fit_config(); cfg.num_iters = 100
+if len(sys.argv) > 5: cfg.debug_launch_shape = int(sys.argv[5])
 if wpp is not None: cfg.pose_prior_weight = wpp
 run = lambda: native.fit_world(m, pr, cfg, list(range(22)), j3d, None, z(B, 3), z(B, 69), z(B, 10), tr0)
 o = run(); torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
-while time.perf_counter() - t0 < 0.3:           # device clock ramp (bench.py does the same)
+while time.perf_counter() - t0 < (0.0 if 'stamp' in ''.join(sys.argv[4:5]) else 0.3):           # device clock ramp (bench.py does the same)
     for _ in range(10): run()
     torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
