@@ -859,7 +859,6 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         const int pQ = bodyQ ? 3 + NC + kq : (goQ ? kq - NR : (betaQ ? 3 + D + (kq - 8) : 3 + D + NB + (kq - 8 - NB)));
         const bool optQ = actQ && ((a.opt_mask >> (bodyQ ? 1 : (goQ ? 0 : (betaQ ? 2 : 3)))) & 1);
         const int fQ = hq ? f[1] : f[0];
-        const bool validQ = hq ? f_valid[1] : f_valid[0];
         float xa[2], ma[2], va[2], pra[2];                             // set A of the two frames
         float xq, mq = 0.f, vq = 0.f, refQ;                            // set B, packed
 #pragma unroll
@@ -1046,20 +1045,31 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         }
         K2B_FSTAMP_ROW_PRINT;
         // ---- results -------------------------------------------------------------------------------------------------------------
+        // (frame numbers and addresses are formed again HERE, from a lane number the compiler cannot trace back: kept from the
+        //  prologue they are a dozen 64-bit values that live in scratch across the whole loop)
+        int lane_r = lane;
+        asm volatile("" : "+v"(lane_r));
         const int P = 3 + D + NB + 3;
+        const int hq_r = lane_r >> 5, kq_r = lane_r & 31;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (!f_valid[h]) continue;
-            a.bp_out[(size_t)f[h] * D + lane] = xa[h];
-            if (lane == 0 && a.loss_out) a.loss_out[f[h]] = losso[h];
-            if (a.grad_out) a.grad_out[(size_t)f[h] * P + pA] = g0o[h];
+            const int fr = blockIdx.x * F + slot0 + h;
+            if (slot0 + h >= F || fr >= a.num_frames) continue;
+            a.bp_out[(size_t)fr * D + lane_r] = xa[h];
+            if (lane_r == 0 && a.loss_out) a.loss_out[fr] = losso[h];
+            if (a.grad_out) a.grad_out[(size_t)fr * P + 3 + lane_r] = g0o[h];
         }
-        if (actQ && validQ) {
-            float* dst = pQ < 3 ? a.go_out + (size_t)fQ * 3 + pQ
-                       : (pQ < 3 + D ? a.bp_out + (size_t)fQ * D + (pQ - 3)
-                       : (pQ < 3 + D + NB ? a.be_out + (size_t)fQ * NB + (pQ - 3 - D) : a.tr_out + (size_t)fQ * 3 + (pQ - 3 - D - NB)));
-            *dst = xq;
-            if (a.grad_out) a.grad_out[(size_t)fQ * P + pQ] = gqo;
+        {
+            const int fr = blockIdx.x * F + slot0 + hq_r;
+            const bool body = kq_r < NR, go = kq_r >= NR && kq_r < 8, beta = kq_r >= 8 && kq_r < 8 + NB;
+            const int pq = body ? 3 + NC + kq_r : (go ? kq_r - NR : (beta ? 3 + D + (kq_r - 8) : 3 + D + NB + (kq_r - 8 - NB)));
+            if (kq_r < nparamB && slot0 + hq_r < F && fr < a.num_frames) {
+                float* dst = pq < 3 ? a.go_out + (size_t)fr * 3 + pq
+                           : (pq < 3 + D ? a.bp_out + (size_t)fr * D + (pq - 3)
+                           : (pq < 3 + D + NB ? a.be_out + (size_t)fr * NB + (pq - 3 - D) : a.tr_out + (size_t)fr * 3 + (pq - 3 - D - NB)));
+                *dst = xq;
+                if (a.grad_out) a.grad_out[(size_t)fr * P + pq] = gqo;
+            }
         }
         return;
     }
