@@ -199,6 +199,34 @@ int k2b_fit_sequence(const k2b_model *model, const k2b_prior *prior, const k2b_f
                      float *loss_out, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * k2b_fit_world_lbfgs — the L-BFGS branch of the fitters, which is the reference's DEFAULT (core/config.py:29
+ * `use_lbfgs=True`; world_space.py:231-247, camera_space.py:144-182,229-267): per frame
+ *     torch.optim.LBFGS(params, max_iter=num_iters, lr=step_size, line_search_fn="strong_wolfe").step(closure)
+ * followed by one more evaluation of the loss at the result (world_space.py:245-246).  The closure (loss and gradient at
+ * the current parameters) is k2b_fit_world's evaluate-only launch under `cfg` (its num_iters / step_size are ignored; weights,
+ * sigma, optimize_mask, freeze_betas, prior_pose_dims ... apply: parameters outside the optimiser get a zero gradient and
+ * never move); the optimiser itself - two-loop recursion over up to `history_size` pairs (<= 0: torch's 100), strong-Wolfe
+ * bracket / zoom with torch's cubic interpolation, tolerance_grad / tolerance_change / max_iter / max_eval = max_iter * 5 / 4
+ * exits - is a state machine on the device, one independent instance per frame (k2b_lbfgs.hip).  The call only queues
+ * launches on `stream` (max_eval + 2 rounds of [closure, optimiser step] + the final evaluation): no host synchronisation,
+ * nothing is read back.  Arguments as k2b_fit_world; preserve_pose / transl_prior_target NULL = the initial body pose /
+ * translation; *_out may alias *_in; loss_out dev [B] and grad_out dev [B][3 + 3(J-1) + NB + 3] (either may be NULL) receive
+ * loss and gradient AT the result.  Frames never interact (torch couples the frames of a batch in one line search; the
+ * reference only ever passes one frame).  At most 192 parameters per frame.
+ * Line searches branch on rounding, so results agree with torch's statistically (and iterate by iterate with the float64
+ * twin core/lbfgs_batched.py while rounding has not yet been amplified): see DESIGN.md.
+ * ------------------------------------------------------------------------------- */
+int k2b_fit_world_lbfgs(const k2b_model *model, const k2b_prior *prior, const k2b_fit_config *cfg,
+                        int32_t num_frames, int32_t num_targets, const int32_t *model_joint_index,
+                        const float *j3d, const float *conf,
+                        const float *global_orient_in, const float *body_pose_in, const float *betas_in,
+                        const float *transl_in, const float *preserve_pose, const float *transl_prior_target,
+                        float *global_orient_out, float *body_pose_out, float *betas_out, float *transl_out,
+                        float *loss_out, float *grad_out,
+                        int32_t max_iter, int32_t history_size, double lr, double tolerance_grad,
+                        double tolerance_change, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * k2b_lbs — full SMPL forward.  Replaces `self.smpl(**kwargs)` (smplx `SMPL.forward`,
  * call sites world_space.py:34,192,278; engine.py:114) for a batch:
  *   joints_out dev [B][J+E][3], vertices_out dev [B][V][3] (NULL: joints only; the E

@@ -160,11 +160,21 @@ class CameraSpaceFitter:
         ``torch.optim.LBFGS(params, max_iter=num_iters, lr=step_size, line_search_fn="strong_wolfe")`` with
         loss and gradient of every closure call from an evaluate-only launch."""
         max_iter, lr = int(self.num_iters), float(self.step_size)
-        for cfg in (cfg1, cfg2):
-            cfg.num_iters, cfg.step_size = 1, 0.0
         B, D = start["global_orient"].shape[0], start["body_pose"].shape[1]
         NB = start["betas"].shape[1]
         preserve = start["body_pose"].clone()                     # camera_space.py:136
+        if getattr(self, "lbfgs_driver", "device") == "device":
+            # both stages on the device (k2b_fit_world_lbfgs): the stages' optimize_mask keeps the parameters outside the
+            # optimiser fixed (stage 1: global_orient + camera translation, camera_space.py:142; stage 2: :219-224)
+            cur = start
+            for cfg, idx, tgt, cf in ((cfg1, idx1, tgt1, None), (cfg2, idx2, tgt2, conf)):
+                cfg.conf_per_frame = int(cf is not None and cf.dim() == 2)
+                cur = native.fit_world_lbfgs(self.smpl.native, self.pose_prior.native, cfg, idx, tgt, cf, cur["global_orient"],
+                                             cur["body_pose"], cur["betas"], cur["transl"], max_iter=max_iter, lr=lr,
+                                             preserve_pose=preserve, transl_prior_target=cam_t0)
+            return {k: cur[k] for k in ("global_orient", "body_pose", "betas", "transl")}
+        for cfg in (cfg1, cfg2):
+            cfg.num_iters, cfg.step_size = 1, 0.0
         rows = {k: [] for k in ("global_orient", "body_pose", "betas", "transl")}
         # (the optimiser's own arithmetic runs on HOST tensors, as in the reference: see WorldSpaceFitter._fit_lbfgs)
         dev = self.device

@@ -243,14 +243,27 @@ class WorldSpaceFitter:
         """LBFGS branch (world_space.py:231-247): ``torch.optim.LBFGS(params, max_iter=num_iters,
         lr=step_size, line_search_fn="strong_wolfe").step(closure)`` per frame, with the closure's
         loss and gradient evaluated by the HIP kernel; final loss re-evaluated afterwards.  One optimiser
-        per frame: identical to the reference for B = 1 (all its API ever passes); for B > 1 the reference
-        couples the frames in one line search, this does not (see the module docstring)."""
+        per frame: for B > 1 the reference couples the frames in one line search, this does not (see the module docstring).
+
+        ``self.lbfgs_driver``: "device" (default since round 4: ``k2b_fit_world_lbfgs``, the optimiser itself on the GPU - every
+        frame of every batch takes the same path, so a frame's result no longer depends on how a sequence was sharded),
+        "host" (the lock-step numpy restatement ``core/lbfgs_batched.py``) or "torch" (``torch.optim.LBFGS`` itself, one frame
+        at a time) - the two host drivers are the device path's twins in the tests."""
         max_iter = int(cfg.num_iters)
-        cfg.num_iters, cfg.step_size = 1, 0.0          # evaluate-only launches
         B, D = go.shape[0], bp.shape[1]
         NB = be.shape[1]
         preserve = bp.clone()                          # world_space.py:159
-        if B > 1:
+        driver = getattr(self, "lbfgs_driver", "device")
+        if driver == "device":
+            # the optimiser's state machine runs in a kernel of its own, one instance per frame; the call only queues launches
+            # (k2b_fit_world_lbfgs: max_eval + 2 rounds of [evaluate-only launch, step launch] + the final loss evaluation)
+            cfg.freeze_betas = int(bool(freeze_betas))
+            out = native.fit_world_lbfgs(self.smpl.native, self.pose_prior.native, cfg, model_idx, tgt, conf, go, bp, be, tr,
+                                         max_iter=max_iter, lr=float(self.step_size), preserve_pose=preserve)
+            self.last_lbfgs_rounds = max_iter * 5 // 4 + 2
+            return out
+        cfg.num_iters, cfg.step_size = 1, 0.0          # evaluate-only launches, driven from the host (the round-2 / round-3 drivers,
+        if B > 1 or driver == "host":                  #  kept as the device path's twins: tests, diagnostics)
             return self._fit_lbfgs_lockstep(cfg, max_iter, model_idx, tgt, conf, go, bp, be, tr, preserve, freeze_betas)
         outs = {k: [] for k in ("global_orient", "body_pose", "betas", "transl", "loss")}
         # The optimiser's own arithmetic (two-loop recursion, strong-Wolfe bookkeeping: hundreds of tiny tensor operations per

@@ -973,6 +973,77 @@ int k2b_fit_sequence(const k2b_model* model, const k2b_prior* prior, const k2b_f
                           go_out, bp_out, be_out, tr_out, loss_out, nullptr, stream, frames_per_sequence, followup_iters);
 }
 
+// L-BFGS branch of the fitters on the device (world_space.py:231-247, camera_space.py:144-182,229-267): per frame
+// torch.optim.LBFGS(max_iter, lr, line_search_fn="strong_wolfe").step(closure), the closure = this library's evaluate-only fit
+// launch, the optimiser = k2b_lbfgs.hip's state machine.  Only launches are queued: max_eval + 2 rounds of [closure, step], then
+// the accepted points go back into the parameter arrays and one more closure launch leaves the final loss (+ gradient).
+int k2b_fit_world_lbfgs(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
+                        const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
+                        const float* bp_in, const float* be_in, const float* tr_in, const float* preserve, const float* tr_prior,
+                        float* go_out, float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out,
+                        int32_t max_iter, int32_t history_size, double lr, double tolerance_grad, double tolerance_change,
+                        void* stream_v) {
+    k2b_model* model = const_cast<k2b_model*>(model_c);
+    if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: model, prior and cfg are required");
+    if (B < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: num_frames=%d", B);
+    if (max_iter < 1 || max_iter > 10000) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: max_iter=%d", max_iter);
+    if (history_size <= 0) history_size = k2b::kLbfgsMaxHistory;
+    if (history_size > k2b::kLbfgsMaxHistory) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world_lbfgs: history_size=%d (at most %d)", history_size, k2b::kLbfgsMaxHistory);
+    if (!(lr > 0.0)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: lr must be positive");
+    if (B == 0) return K2B_OK;
+    if (!go_in || !bp_in || !be_in || !tr_in || !go_out || !bp_out || !be_out || !tr_out)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: NULL parameter buffer");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int NB = model->NB, D = 3 * (model->J - 1), P = 3 + D + NB + 3;
+    if (P > 192) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world_lbfgs: %d parameters per frame (at most 192)", P);
+    const int H = history_size < max_iter ? history_size : max_iter;      // (a fit makes at most max_iter - 1 pairs)
+    const int max_eval = max_iter * 5 / 4;                               // torch's default
+    // stream-ordered workspace: optimiser state, closure results, the preserve pose and the translation prior's centre (their
+    // defaults are the INITIAL parameters, which the parameter arrays stop holding after the first step)
+    size_t off_si = 0, off_sv = 0;
+    const size_t n_state = k2b::lbfgs_state_bytes(B, P, H, &off_si, &off_sv);
+    const size_t n_f = (size_t)B * P + B + (size_t)B * D + (size_t)B * 3;
+    unsigned char* ws = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&ws, n_state + n_f * sizeof(float), stream));
+    auto cleanup = [&](int rc) { (void)hipFreeAsync(ws, stream); return rc; };
+#define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_world_lbfgs: HIP call failed")); } } while (0)
+    float* gbuf = reinterpret_cast<float*>(ws + n_state);
+    float *lbuf = gbuf + (size_t)B * P, *pres = lbuf + B, *trp = pres + (size_t)B * D;
+    K2B_TRY_WS(hipMemsetAsync(ws, 0, off_sv, stream));                  // scalars and integers: phase INIT (vectors are written before they are read)
+    K2B_TRY_WS(hipMemcpyAsync(pres, preserve ? preserve : bp_in, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    K2B_TRY_WS(hipMemcpyAsync(trp, tr_prior ? tr_prior : tr_in, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    const struct { const float* src; float* dst; size_t n; } cp[] = {
+        {go_in, go_out, (size_t)B * 3}, {bp_in, bp_out, (size_t)B * D}, {be_in, be_out, (size_t)B * NB}, {tr_in, tr_out, (size_t)B * 3}};
+    for (const auto& c : cp)
+        if (c.src != c.dst) K2B_TRY_WS(hipMemcpyAsync(c.dst, c.src, c.n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    k2b_fit_config ec = *cfg;
+    ec.num_iters = 1;
+    ec.step_size = 0.0;                                                  // evaluate-only: the closure
+    auto closure = [&](float* loss, float* grad) {
+        return fit_world_impl(model_c, prior, &ec, B, K, model_joint_index, j3d, conf, go_out, bp_out, be_out, tr_out, pres,
+                              (tr_prior || cfg->transl_prior_weight != 0.0f) ? trp : nullptr,   // (the tree kernel has no translation prior)
+                              go_out, bp_out, be_out, tr_out, loss, grad, stream_v, 1, 0);
+    };
+    k2b::LbfgsArgs la{};
+    la.B = B; la.P = P; la.D = D; la.NB = NB; la.H = H;
+    la.max_iter = max_iter; la.max_eval = max_eval;
+    la.lr = lr; la.tol_g = tolerance_grad; la.tol_c = tolerance_change;
+    la.go = go_out; la.bp = bp_out; la.be = be_out; la.tr = tr_out;
+    la.loss_in = lbuf; la.grad_in = gbuf;
+    la.sd = reinterpret_cast<double*>(ws); la.si = reinterpret_cast<int*>(ws + off_si); la.sv = reinterpret_cast<float*>(ws + off_sv);
+    const int rounds = max_eval + 2;
+    for (int r = 0; r < rounds; ++r) {
+        if (const int rc = closure(lbuf, gbuf); rc != K2B_OK) return cleanup(rc);
+        K2B_TRY_WS(k2b::launch_lbfgs_step(la, stream));
+    }
+    la.finalize = 1;
+    K2B_TRY_WS(k2b::launch_lbfgs_step(la, stream));
+    // loss (and gradient) at the result (world_space.py:245-246 evaluates the loss once more behind the optimiser)
+    if (const int rc = closure(loss_out ? loss_out : lbuf, grad_out); rc != K2B_OK) return cleanup(rc);
+#undef K2B_TRY_WS
+    return cleanup(K2B_OK);
+}
+
 namespace {
 // grow-only per-model workspace of the per-frame LBS operands (caller holds m->mu)
 int reserve_lbs_workspace(k2b_model* m, int bpad) {

@@ -240,6 +240,22 @@ inline hipError_t ensure_dynamic_lds(Kernel kernel, std::atomic<unsigned long lo
     return e;
 }
 
+// ---- device-resident L-BFGS (k2b_lbfgs.hip): one state machine per frame, one closure result consumed per step launch ----------
+constexpr int kLbfgsMaxHistory = 100;    // torch.optim.LBFGS's default history_size
+struct LbfgsArgs {
+    int B, P, D, NB, H;                  // frames, parameters per frame (3 + D + NB + 3), pose / shape widths, history slots
+    int max_iter, max_eval;
+    double lr, tol_g, tol_c;             // lr, tolerance_grad, tolerance_change
+    float *go, *bp, *be, *tr;            // the point to evaluate next, in the closure's own parameter arrays (in / out)
+    const float *loss_in, *grad_in;      // closure result at that point: [B], [B][P]
+    double* sd;                          // state: scalars, integers, vectors (lbfgs_state_bytes)
+    int* si;
+    float* sv;
+    int finalize;                        // 1: no result consumed, every frame's accepted point -> parameter arrays
+};
+size_t lbfgs_state_bytes(int B, int P, int H, size_t* off_si, size_t* off_sv);
+hipError_t launch_lbfgs_step(const LbfgsArgs& a, hipStream_t stream);
+
 // Geodesic angle (degrees) between n pairs of axis-angle rotations (evaluation metric, k2b_metrics.hip).
 hipError_t launch_angular_error(const float* pred, const float* gt, float* out, long long n, hipStream_t stream);
 

@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
     "k2b_model_joint_basis", "k2b_model_reserve", "k2b_debug_read_dump", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
     "k2b_fit_world", "k2b_fit_sequence", "k2b_lbs", "k2b_vertex_term", "k2b_adam_step", "k2b_angular_error_deg",
+    "k2b_fit_world_lbfgs",
 )
 
 
@@ -104,6 +105,9 @@ def load_library():
     lib.k2b_fit_sequence.argtypes = [vp, vp, C.POINTER(FitConfigC)] + [C.c_int32] * 4 + [ip] + [fp] * 11 + [vp]
     lib.k2b_lbs.restype = C.c_int
     lib.k2b_lbs.argtypes = [vp, C.c_int32] + [fp] * 6 + [vp]
+    lib.k2b_fit_world_lbfgs.restype = C.c_int
+    lib.k2b_fit_world_lbfgs.argtypes = ([vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 14 +
+                                        [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, vp])
     lib.k2b_vertex_term.restype = C.c_int
     lib.k2b_vertex_term.argtypes = [vp, C.c_int32, C.c_int32, ip, fp, fp, C.c_float, C.c_float] + [fp] * 6 + [vp]
     lib.k2b_adam_step.restype = C.c_int
@@ -310,6 +314,51 @@ def fit_world(model: NativeModel, prior: NativePrior, cfg: FitConfigC, model_joi
             C.c_void_p(out["betas"].data_ptr()), C.c_void_p(out["transl"].data_ptr()),
             C.c_void_p(out["loss"].data_ptr()),
             C.c_void_p(out["grad"].data_ptr()) if want_grad else None, stream), "k2b_fit_world")
+    return out
+
+
+def fit_world_lbfgs(model: NativeModel, prior: NativePrior, cfg: FitConfigC, model_joint_index: Sequence[int],
+                    j3d: torch.Tensor, conf: Optional[torch.Tensor], global_orient: torch.Tensor, body_pose: torch.Tensor,
+                    betas: torch.Tensor, transl: torch.Tensor, *, max_iter: int, lr: float,
+                    preserve_pose: Optional[torch.Tensor] = None, transl_prior_target: Optional[torch.Tensor] = None,
+                    want_grad: bool = False, history_size: int = 100, tolerance_grad: float = 1e-7,
+                    tolerance_change: float = 1e-9):
+    """The L-BFGS branch on the device (``k2b_fit_world_lbfgs``): per frame ``torch.optim.LBFGS(max_iter, lr,
+    line_search_fn="strong_wolfe").step(closure)`` with this library's evaluate-only launch as the closure and the optimiser's
+    state machine in a kernel of its own; only launches are queued on the current stream.  Returns the dict of ``fit_world``
+    (``loss`` = the loss at the result, ``grad`` with `want_grad`)."""
+    dev = model.device
+    B, K = j3d.shape[0], j3d.shape[1]
+    D = 3 * (model.num_joints - 1)
+    idx = _host_i32(np.asarray(list(model_joint_index)))
+    if idx.shape != (K,):
+        raise ValueError(f"model_joint_index has {idx.shape[0]} entries for {K} targets")
+    conf_p = None
+    if conf is not None:
+        conf_p = _dev(conf, "conf", dev, (B, K) if cfg.conf_per_frame else (K,))
+    out = {
+        "global_orient": torch.empty((B, 3), dtype=torch.float32, device=dev),
+        "body_pose": torch.empty((B, D), dtype=torch.float32, device=dev),
+        "betas": torch.empty((B, model.num_betas), dtype=torch.float32, device=dev),
+        "transl": torch.empty((B, 3), dtype=torch.float32, device=dev),
+        "loss": torch.empty((B,), dtype=torch.float32, device=dev),
+    }
+    if want_grad:
+        out["grad"] = torch.empty((B, 3 + D + model.num_betas + 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _check(load_library().k2b_fit_world_lbfgs(
+            model.handle, prior.handle, C.byref(cfg), B, K, _np_ptr(idx),
+            _dev(j3d, "j3d", dev, (B, K, 3)), conf_p,
+            _dev(global_orient, "global_orient", dev, (B, 3)), _dev(body_pose, "body_pose", dev, (B, D)),
+            _dev(betas, "betas", dev, (B, model.num_betas)), _dev(transl, "transl", dev, (B, 3)),
+            _dev(preserve_pose, "preserve_pose", dev, (B, D)),
+            _dev(transl_prior_target, "transl_prior_target", dev, (B, 3)),
+            C.c_void_p(out["global_orient"].data_ptr()), C.c_void_p(out["body_pose"].data_ptr()),
+            C.c_void_p(out["betas"].data_ptr()), C.c_void_p(out["transl"].data_ptr()),
+            C.c_void_p(out["loss"].data_ptr()), C.c_void_p(out["grad"].data_ptr()) if want_grad else None,
+            int(max_iter), int(history_size), float(lr), float(tolerance_grad), float(tolerance_change), stream),
+            "k2b_fit_world_lbfgs")
     return out
 
 
