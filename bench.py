@@ -43,7 +43,7 @@ sys.path.insert(0, str(REPO))
 FIT_FLOP_PER_FRAME_ITER = {"smpl": 0.11e6, "smplx": 0.106e6}
 FP32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 HBM_PEAK_GBS = 8000.0
-ROUND = "r03"
+ROUND = "r04"
 LBS_KERNELS = {"smpl": "k2b_pose_setup_kernel+k2b_lbs_stream_kernel", "smplx": "k2b_pose_setup_kernel+k2b_lbs_tile_kernel"}
 PREWARM_S = 0.3        # seconds of untimed load before the warm-up steps (device clock ramp, see measure())
 
@@ -210,6 +210,21 @@ def read_traffic(model_kind, frames):
         if fit is not None or lbs is not None:
             return fit, lbs, name
     return None, None, None
+
+
+def read_sq(model_kind, frames):
+    """Issue-side counters of the fit kernel at this size, derived from the committed SQ passes (profiles/<ROUND>_sq_fit_*.csv,
+    tools/pmc_fit.sh): `valu_active_frac` = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of the waves' lifetime with a vector
+    instruction executing), `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x launch cycles at the 2.4 GHz peak clock)."""
+    if model_kind != "smpl":
+        return None
+    f = REPO / "profiles" / f"{ROUND}_sq_fit.json"
+    if not f.exists():
+        return None
+    try:
+        return json.loads(f.read_text()).get(str(frames))
+    except Exception:
+        return None
 
 
 def spawn_ranks(n):
@@ -459,6 +474,9 @@ def main():
             line["exchange_ms"] = round(r["exchange_ms"], 4)    # what the step waits for the collectives behind the forward
         if traffic_src:
             line["roofline"]["traffic_source"] = line["roofline_lbs"]["traffic_source"] = "profiles/" + traffic_src
+        sq = read_sq(args.model, F)
+        if sq:
+            line["roofline"].update({k: sq[k] for k in ("valu_active_frac", "mfma_busy_frac", "wait_any_frac", "sq_source") if k in sq})
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline and args.model == "smpl":
             line["cpu_baseline"] = cpu_baseline(args.iters, args.cpu_runs)

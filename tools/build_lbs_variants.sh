@@ -14,6 +14,6 @@ for spec in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_api.hip -o /tmp/k2b_api_$name.o
   /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_lbs_stream.hip -o /tmp/k2b_lbs_stream_$name.o
   /opt/rocm/bin/hipcc $FLAGS $defs -c k2b_lbs.hip -o /tmp/k2b_lbs_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libk2b_$name.so /tmp/k2b_api_$name.o k2b_fit.o k2b_fit_tree.o /tmp/k2b_lbs_$name.o /tmp/k2b_lbs_stream_$name.o k2b_precompute.o k2b_metrics.o k2b_vertex.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libk2b_$name.so /tmp/k2b_api_$name.o k2b_fit.o k2b_fit_tree.o /tmp/k2b_lbs_$name.o /tmp/k2b_lbs_stream_$name.o k2b_precompute.o k2b_metrics.o k2b_vertex.o k2b_lbfgs.o
   echo "built tools/libk2b_$name.so ($defs)"
 done

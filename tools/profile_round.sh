@@ -26,4 +26,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${c}_x1024 -- python3 $R/bench.py --model smplx --steps 5 --warmup 2 --total-frames 1024 --no-cpu-baseline --no-weak-line > /dev/null 2> $O/${c}_x1024.err
 done
 echo "pmc passes done"
+bash $R/tools/pmc_fit.sh ${TAG}_4096 4096 > $O/sq_fit_4096.txt 2>&1 || true
+bash $R/tools/pmc_fit.sh ${TAG}_1024 1024 > $O/sq_fit_1024.txt 2>&1 || true
+echo "sq passes done"
 cat $O/bench_default.json

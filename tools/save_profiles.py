@@ -2,7 +2,7 @@
 reads) and write profiles/traffic_<ROUND>.json.  usage: python tools/save_profiles.py TAG [ROUND=r03]"""
 import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 O = f'gpurun_out/prof_{tag}'
 P = f'profiles/{rnd}_final_'
 for f in glob.glob(P + '*'): os.remove(f)
@@ -51,3 +51,26 @@ for n in ('bench_default', 'bench_1024', 'bench_smplx_1024', 'bench_default_unde
     b = json.load(open(f'{P}{n}.json'))
     print(n, b['value'], b['ms_per_step'], b['roofline']['avg_launch_ms'], b['roofline']['frac'], b['roofline_lbs']['avg_launch_ms'],
           b['roofline_lbs']['frac'], b.get('cpu_baseline', {}).get('value'))
+
+# SQ counter passes of the fit kernel (tools/pmc_fit.sh, run by profile_round.sh): raw per-dispatch rows + derived fractions
+sq = {}
+for fr in ("4096", "1024"):
+    rawf, sumf = f'gpurun_out/pmc_{tag}_{fr}.raw.csv', f'gpurun_out/pmc_{tag}_{fr}.summary.json'
+    if not (os.path.exists(rawf) and os.path.exists(sumf)):
+        continue
+    shutil.copy(rawf, f'profiles/{rnd}_sq_fit_{fr}.csv')
+    a = json.load(open(sumf))["per_launch_average"]
+    b = json.load(open(f'{P}bench_default.json' if fr == "4096" else f'{P}bench_1024.json'))
+    ms = b['roofline']['avg_launch_ms']
+    sq[fr] = {
+        "valu_active_frac": round(a["SQ_ACTIVE_INST_VALU"] / a["SQ_WAVE_CYCLES"], 4),
+        "wait_any_frac": round(a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"], 4),
+        "mfma_busy_frac": round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * ms * 1e-3 * 2.4e9), 4),
+        "insts_valu_per_launch": a["SQ_INSTS_VALU"], "insts_mfma_per_launch": a["SQ_INSTS_MFMA"], "insts_lds_per_launch": a["SQ_INSTS_LDS"],
+        "waves_per_launch": a["SQ_WAVES"], "lds_idx_active_cycles": a["SQ_LDS_IDX_ACTIVE"], "lds_bank_conflict_cycles": a["SQ_LDS_BANK_CONFLICT"],
+        "launch_ms_in_bench": ms,
+        "sq_source": f"profiles/{rnd}_sq_fit_{fr}.csv (tools/pmc_fit.sh: five rocprofv3 --pmc passes, last eight dispatches of each)",
+    }
+if sq:
+    json.dump(sq, open(f'profiles/{rnd}_sq_fit.json', 'w'), indent=1)
+    print(sq)
