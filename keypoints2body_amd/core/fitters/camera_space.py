@@ -17,10 +17,12 @@ differ only in the fit configuration:
   = camera translation, ``loss`` = the loss re-evaluated at the fitted parameters with joint
   weight 600 and no preserve term (an evaluate-only launch: one iteration with step size 0).
 
-``use_lbfgs=True`` (``camera_space.py:144-182, 229-267``) keeps ``torch.optim.LBFGS`` (strong Wolfe) as the
-outer algorithm of both stages, as the reference does; every closure evaluation is one evaluate-only
-launch of the same kernel with the stage's configuration (loss and analytic gradient, no autograd
-graph).  L-BFGS couples the parameters it is given, so that mode fits one frame at a time.
+``use_lbfgs=True`` (``camera_space.py:144-182, 229-267``) keeps L-BFGS (strong Wolfe) as the outer algorithm of both
+stages, as the reference does; every closure evaluation is one evaluate-only launch of the same kernel with the stage's
+configuration (loss and analytic gradient, no autograd graph) and, since round 4, the optimiser's state machine runs on
+the device as well (``k2b_fit_world_lbfgs``: one independent optimiser per frame; the stages' ``optimize_mask`` keeps the
+parameters outside the optimiser fixed).  ``lbfgs_driver = "torch"`` selects the host-driven twin (``torch.optim.LBFGS``
+itself, one frame at a time).
 
 Vertex-selected joints among ``target_model_indices`` (model index >= 24) are handled inside ``k2b_fit_world`` in
 both stages (two launches per iteration queued by the one call: fused kernel evaluate-only + vertex term with Adam tail).

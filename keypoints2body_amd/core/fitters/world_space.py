@@ -8,16 +8,15 @@ class validates its inputs, uploads them and makes ONE call into ``libk2b.so``
 (``k2b_fit_world``: all iterations fused in one kernel, one frame per wavefront) plus
 one ``k2b_lbs`` call for the final vertices/joints (``world_space.py:258-278``).
 
-``use_lbfgs=True`` (the reference's default, ``world_space.py:231-247``) keeps
-``torch.optim.LBFGS`` (strong Wolfe) as the outer algorithm, exactly as the reference does, but its
-closure no longer builds an autograd graph: loss and gradient of every evaluation come from an
-evaluate-only launch of the same kernel (``step_size = 0``, ``grad_out``); the optimiser's own vectors live on the
-host (one upload of the parameters and one download of [gradient | loss] per closure call).  L-BFGS couples all
-parameters it is given: the reference hands ONE optimiser the parameters of the whole batch, so for
-B > 1 its frames share a line search (a batch is then NOT B independent fits); the API only ever
-calls it with B = 1 (``api/sequence.py:215``).  This class runs one L-BFGS per frame, which equals
-the reference for B = 1 and deliberately differs (independent frames) for B > 1 - and for B > 1 the per-frame optimisers
-advance in lock-step (``core/lbfgs_batched.py``) so that one launch per round serves every frame.
+``use_lbfgs=True`` (the reference's default, ``world_space.py:231-247``) keeps L-BFGS with the strong-Wolfe line search
+as the outer algorithm, exactly as the reference does, but its closure no longer builds an autograd graph: loss and
+gradient of every evaluation come from an evaluate-only launch of the same kernel (``step_size = 0``, ``grad_out``).
+Since round 4 the optimiser itself runs on the device too (``k2b_fit_world_lbfgs``, ``csrc/k2b_lbfgs.hip``: torch's
+``LBFGS.step`` / ``_strong_wolfe`` restated as a per-frame state machine; the host only queues launches).  L-BFGS couples
+all parameters it is given: the reference hands ONE optimiser the parameters of the whole batch, so for B > 1 its frames
+share a line search; the API only ever calls it with B = 1 (``api/sequence.py:215``).  This class runs one independent
+optimiser per frame, which equals the reference for B = 1 and deliberately differs (independent frames) for B > 1.
+``lbfgs_driver = "host" | "torch"`` select the host-driven twins (``core/lbfgs_batched.py``; ``torch.optim.LBFGS`` itself).
 
 Differences, all deliberate and documented in DESIGN.md:
 
