@@ -195,7 +195,7 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
     # independent frames: all start from `prev` (api/sequence.py:214-281 with use_previous_frame_init=False)
     if frame_cfg.coordinate_mode == "world" and prev.transl is None:
         prev = _with_root_aligned_transl(prev, xyz[0:1], model, frame_cfg, device)
-    if not hasattr(est.fitter, "fit_batch"):          # camera-space fitter: one call per frame
+    if not hasattr(est.fitter, "fit_batch"):          # (a plug-in estimator without a batched entry point: one call per frame)
         for idx in range(T):
             results.append(engine.fit_frame(init_params=prev, j3d=xyz[idx: idx + 1], conf_3d=conf[idx], seq_ind=idx,
                                             target_model_indices=model_indices))

@@ -96,10 +96,15 @@ class CameraSpaceFitter:
         cfg2.optimize_mask = 15 if fit_betas else 11
         return cfg1, cfg2, fit_betas
 
-    def fit_frame(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
+    def fit_batch(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
                   seq_ind: int = 0, target_model_indices: Optional[torch.Tensor] = None,
                   joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = True,
-                  init_cam_t: Optional[torch.Tensor] = None) -> BodyModelFitResult:
+                  init_cam_t: Optional[torch.Tensor] = None, per_frame_conf: bool = False, want_vertices: bool = True,
+                  run_forward: bool = True):
+        """Both stages for B independent frames (two fused launches for the whole batch + one evaluate-only launch for the
+        reported loss): ``(params dict of (B, .) tensors - ``transl`` = the camera translation -, joints, vertices,
+        per-frame loss)``; ``run_forward=False`` leaves the final forward to the caller (``final_forward``), as the sharded
+        sequence path wants it.  Every frame's result is that of its own single-frame ``fit_frame`` call, bit for bit."""
         J = self.smpl.num_joints
         go = self._dev(init_params.global_orient, 3)
         bp = self._dev(init_params.body_pose, 3 * (J - 1))
@@ -119,6 +124,8 @@ class CameraSpaceFitter:
             targets = j3d.contiguous()
             stage1_idx, stage1_tgt, depth_w = model_idx, targets, 100.0          # camera_space.py:199-210
         conf = None if conf_3d is None else torch.as_tensor(conf_3d, dtype=torch.float32).to(self.device).contiguous()
+        if conf is not None and conf.dim() == 2 and not per_frame_conf:
+            conf = conf[0].contiguous()                                          # (the reference reads row 0 only)
 
         # initial camera translation (camera_space.py:110-134)
         if init_cam_t is None:
@@ -134,6 +141,7 @@ class CameraSpaceFitter:
         def fit(cfg, idx, tgt, cf, p):
             # (vertex-selected joints among the targets are handled inside k2b_fit_world)
             cur = (p["global_orient"], p["body_pose"], p["betas"], p["transl"])
+            cfg.conf_per_frame = int(cf is not None and cf.dim() == 2)
             return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt, cf, *cur,
                                     transl_prior_target=cam_t0)
 
@@ -149,12 +157,30 @@ class CameraSpaceFitter:
         cfg = native.default_fit_config()
         cfg.num_iters, cfg.step_size, cfg.joint_loss_weight = 1, 0.0, 600.0
         final = fit(cfg, model_idx, targets, conf, s2)
+        out = {k: s2[k] for k in ("global_orient", "body_pose", "betas", "transl")}
+        out["loss"] = final["loss"]
+        if not run_forward:
+            return out, None, None, out["loss"]
+        joints, verts = self.final_forward(out, want_vertices=want_vertices)
+        return out, joints, verts, out["loss"]
 
-        joints, verts = self.smpl.native.lbs(s2["global_orient"], s2["body_pose"], s2["betas"], None)
-        return BodyModelFitResult(
-            params=SMPLData(betas=s2["betas"], global_orient=s2["global_orient"], body_pose=s2["body_pose"],
-                            transl=s2["transl"]),
-            vertices=verts, joints=joints, loss=final["loss"].sum())
+    def final_forward(self, out, want_vertices=True):
+        """Final forward of the reference (camera_space.py:300-314): model-space joints / vertices - the camera translation
+        is part of the parameters, not applied to the mesh."""
+        return self.smpl.native.lbs(out["global_orient"], out["body_pose"], out["betas"], None, want_vertices=want_vertices)
+
+    def result_params(self, out, init_params=None, rows: Optional[slice] = None):
+        sl = slice(None) if rows is None else rows
+        return SMPLData(betas=out["betas"][sl], global_orient=out["global_orient"][sl], body_pose=out["body_pose"][sl],
+                        transl=out["transl"][sl])
+
+    def fit_frame(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
+                  seq_ind: int = 0, target_model_indices: Optional[torch.Tensor] = None,
+                  joint_loss_weight: float = 600.0, pose_preserve_weight: float = 5.0, freeze_betas: bool = True,
+                  init_cam_t: Optional[torch.Tensor] = None) -> BodyModelFitResult:
+        out, joints, verts, loss = self.fit_batch(init_params, j3d, conf_3d, seq_ind, target_model_indices, joint_loss_weight,
+                                                  pose_preserve_weight, freeze_betas, init_cam_t=init_cam_t)
+        return BodyModelFitResult(params=self.result_params(out), vertices=verts, joints=joints, loss=loss.sum())
 
     # ------------------------------------------------------------------------------------------------
     def _two_stages_lbfgs(self, cfg1, cfg2, fit_betas, idx1, tgt1, idx2, tgt2, conf, start, cam_t0):
