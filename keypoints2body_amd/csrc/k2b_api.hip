@@ -481,7 +481,7 @@ int k2b_prior_create(k2b_prior** out, int32_t M, int32_t D, const float* means, 
     for (int m = 0; m < M; ++m) {
         for (int cc = 0; cc < NR; ++cc)
             for (int col = 0; col < NC; ++col)
-                pa[((size_t)(2 * cc + ((col >> 2) & 1)) * 64 + 8 * m + (col >> 3)) * 4 + (col & 3)] = P(m, NC + cc, col);
+                pa[((size_t)m * NR + cc) * NC + col] = P(m, NC + cc, col);       // [m][rim row][column]: lane = column, conflict-free 4-byte reads
         for (int r = 0; r < NC; ++r) {
             cmu[(size_t)m * 2 * NC + r] = means[m * D + r];
             cmu[(size_t)m * 2 * NC + NC + r] = (float)c[(size_t)m * D + r];

@@ -72,8 +72,8 @@ constexpr int MAXS = 16;                // frame slots per workgroup (= MFMA col
 constexpr int MG = kPriorMaxGauss;      // 8
 constexpr int NC = 64;                  // core rows / columns of a component handled by the matrix cores
 constexpr int NR = D - NC;              // 5 rim rows / columns
-// LDS (floats): rim rows of P as [10][64 lanes][4] (lane 8m + s: columns 8s..8s+7 of rows 64..68 of
-// component m), then mu | c = P mu of the core rows [m][2][64], then the per-frame-slot blocks:
+// LDS (floats): rim rows of P as [m][5 rim rows][64 columns] (read transposed - lane = column - for the arg-min component's
+// rim columns), then mu | c = P mu of the core rows [m][2][64], then the per-frame-slot blocks:
 // parameters (row role -> tree / component roles), gradients (tree -> row), theta[0..63] as f16 hi | lo.
 constexpr int RIM_FLOATS = 2 * NR * 64 * 4;
 constexpr int CMU_FLOATS = MG * 2 * NC;
@@ -251,6 +251,8 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
     const float* cmu = lds + RIM_FLOATS;                                // [m][mu | c][64]
     const half8* rimfrag = reinterpret_cast<const half8*>(lds + RIM_FLOATS + CMU_FLOATS);   // [m][fragment 4][21 entries]
     float* slots = lds + RIM_FLOATS + CMU_FLOATS + RF_FLOATS;
+    for (int i = tid; i < MAXS * SLOT; i += blockDim.x) slots[i] = 0.f;      // (strip tails are read in 16-byte pieces: keep them finite)
+    __syncthreads();                                                          // (before the first publish)
     float* qx = slots + MAXS * SLOT;                           // [slot][m]   core part of d^T P_m d
     float* yx = qx + MAXS * MG;                                // [slot][m][64] (stride YX_STRIDE)  core part of y_m, rows 0..63
     // J_dirs differences of every tree lane, [lane][3][NBT] at a stride that spreads the lanes' b128 reads
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
     float* rcl = wx + WX_FLOATS;                                      // [8][64]: row_const (16-wave shapes)
     constexpr bool RC_IN_LDS = WIDE16;
     if (RC_IN_LDS)
-        for (int i = tid; i < RC_FLOATS; i += blockDim.x) rcl[i] = a.row_const[i];
+        for (int i = tid; i < RC_FLOATS; i += blockDim.x) rcl[(i & 63) * 8 + (i >> 6)] = a.row_const[i];   // [lane][8]: two 16-byte reads per lane
     constexpr bool DD_IN_LDS = (PAIR && !SPLIT) || WIDE16;
     if (DD_IN_LDS) {
         for (int i = tid; i < 64 * DDN; i += blockDim.x) {
@@ -311,8 +313,6 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         kB_r = a.row_const[6 * 64 + lane];    // (P_BA mu_A)[gs]
         muB_r = a.row_const[7 * 64 + lane];   // mu[64 + gs]
     }
-    // float4 index of P_m[64 + c][lane] (= P_m[lane][64 + c]) in the rim image, without the m and c terms
-    const int rimcol = (((lane >> 2) & 1) * 64 + (lane >> 3)) * 4 + (lane & 3);
 
     // angle prior: sign (0 = not a prior index) for the set-A parameter of this lane
     float angA = 0.f;
@@ -554,12 +554,19 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
     auto tree_pass = [&](bool last) __attribute__((always_inline)) {
         // ---- b/d. tree-layout reads, J(beta), Rodrigues ---------------------------------------------
         const Vec3 th = {xs_t[thoff], xs_t[thoff + 1], xs_t[thoff + 2]};
-        const Vec3 tr = {xs_t[XS_TRANSL], xs_t[XS_TRANSL + 1], xs_t[XS_TRANSL + 2]};
+        const float4 tr4 = *reinterpret_cast<const float4*>(xs_t + XS_TRANSL);          // transl | (joint loss slot)
+        const Vec3 tr = {tr4.x, tr4.y, tr4.z};
         Vec3 dj;
         {
             float beta[NBT];
 #pragma unroll
-            for (int k = 0; k < NBT; ++k) beta[k] = xs_t[XS_BETA + (k < NB ? k : 0)];
+            for (int q = 0; q < (NBT + 3) / 4; ++q) {      // 16-byte reads; entries beyond NB are zeros (strips cleared at kernel start)
+                const float4 b4 = *reinterpret_cast<const float4*>(xs_t + XS_BETA + 4 * q);
+                if (4 * q < NBT) beta[4 * q] = b4.x;
+                if (4 * q + 1 < NBT) beta[4 * q + 1] = b4.y;
+                if (4 * q + 2 < NBT) beta[4 * q + 2] = b4.z;
+                if (4 * q + 3 < NBT) beta[4 * q + 3] = b4.w;
+            }
             float dd[4 * DDQ];
             read_dd(dd);
             float e[3];
@@ -743,10 +750,10 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
             {
                 float pbb[NR], cB, kB, muB;
 #pragma unroll
-                for (int k = 0; k < NR; ++k) pbb[k] = RC_IN_LDS ? rcl[k * 64 + lane] : pbb_r[k];
-                cB = RC_IN_LDS ? rcl[5 * 64 + lane] : cB_r;
-                kB = RC_IN_LDS ? rcl[6 * 64 + lane] : kB_r;
-                muB = RC_IN_LDS ? rcl[7 * 64 + lane] : muB_r;
+                for (int k = 0; k < NR; ++k) pbb[k] = RC_IN_LDS ? rcl[lane * 8 + k] : pbb_r[k];
+                cB = RC_IN_LDS ? rcl[lane * 8 + 5] : cB_r;
+                kB = RC_IN_LDS ? rcl[lane * 8 + 6] : kB_r;
+                muB = RC_IN_LDS ? rcl[lane * 8 + 7] : muB_r;
                 const float wm = wx[slot * 64 + lane], tB = xs[tBoff];
                 const float vB = pbb[0] * t64.x + pbb[1] * t64.y + pbb[2] * t64.z + pbb[3] * t64.w + pbb[4] * t68;
                 const float y = wm + vB - cB;
@@ -765,8 +772,8 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
             const int mstar = hit ? (int)(__builtin_ctzll(hit) >> 3) : 0;
             // rows 0..63: core part from the component wave + the rim columns, P[l][64 + c] = P[64 + c][l]
             yA = yx[slot * YX_STRIDE + mstar * NC + lane];
-            const float* rimf = lds + mstar * 32 + rimcol;
-            yA += rimf[0 * 512] * t64.x + rimf[1 * 512] * t64.y + rimf[2 * 512] * t64.z + rimf[3 * 512] * t64.w + rimf[4 * 512] * t68;
+            const float* rimf = lds + mstar * (NR * NC) + lane;
+            yA += rimf[0 * NC] * t64.x + rimf[1 * NC] * t64.y + rimf[2 * NC] * t64.z + rimf[3 * NC] * t64.w + rimf[4 * NC] * t68;
             yBs = bperm((8 * mstar + (lane < NR ? lane : 0)) * 4, yBv);     // rows 64 + lane for lanes < 5
         }
         // Branch-free: every lane evaluates  c_y y + 2 c_q (x - ref)  with its own coefficients (set A: mixture
@@ -978,6 +985,8 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
             // ---- priors: per frame in the (component, rim row) lane layout, then the set-A gradient; set B once for both --------
             float gpa[2] = {0.f, 0.f}, lossp[2] = {0.f, 0.f}, bestv[2] = {0.f, 0.f};
             float yQ = 0.f;
+            // per-lane rim constants (P_BB row, c_B, P_BA mu_A, mu_B): two 16-byte LDS reads per iteration, for both frames
+            const float4 rc0 = *reinterpret_cast<const float4*>(rcl + lane * 8), rc1 = *reinterpret_cast<const float4*>(rcl + lane * 8 + 4);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (slot0 + h >= F) continue;
@@ -990,9 +999,9 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                     float yBv, qrim;
                     {
                         const float wm = wx[slot * 64 + lane], tB = xs[tBoff];
-                        const float vB = rcl[0 * 64 + lane] * t64.x + rcl[1 * 64 + lane] * t64.y + rcl[2 * 64 + lane] * t64.z + rcl[3 * 64 + lane] * t64.w + rcl[4 * 64 + lane] * t68;
-                        const float y = wm + vB - rcl[5 * 64 + lane];
-                        const float term = tB * (wm - rcl[6 * 64 + lane]) + (tB - rcl[7 * 64 + lane]) * y;
+                        const float vB = rc0.x * t64.x + rc0.y * t64.y + rc0.z * t64.z + rc0.w * t64.w + rc1.x * t68;
+                        const float y = wm + vB - rc1.y;
+                        const float term = tB * (wm - rc1.z) + (tB - rc1.w) * y;
                         yBv = gs < NR ? y : 0.f;
                         qrim = group8_sum(gs < NR ? term : 0.f);
                     }
@@ -1003,8 +1012,8 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64(val == best);
                     const int mstar = hit ? (int)(__builtin_ctzll(hit) >> 3) : 0;
                     yA = yx[slot * YX_STRIDE + mstar * NC + lane];
-                    const float* rimf = lds + mstar * 32 + rimcol;
-                    yA += rimf[0 * 512] * t64.x + rimf[1 * 512] * t64.y + rimf[2 * 512] * t64.z + rimf[3 * 512] * t64.w + rimf[4 * 512] * t68;
+                    const float* rimf = lds + mstar * (NR * NC) + lane;
+                    yA += rimf[0 * NC] * t64.x + rimf[1 * NC] * t64.y + rimf[2 * NC] * t64.z + rimf[3 * NC] * t64.w + rimf[4 * NC] * t68;
                     const float yb = bperm((8 * mstar + (kq < NR ? kq : 0)) * 4, yBv);      // rows 64 + kq, for both halves
                     yQ = hq == h ? yb : yQ;
                 }

@@ -18,9 +18,7 @@ constexpr int kFitMaxWaves = 8;     // frames (waves) per workgroup
 constexpr int kMaxJoints = 64;
 constexpr int kMaxRounds = 4;       // pointer-doubling rounds: tree depth < 2^4
 constexpr int kLaneTabStride = 8;   // ints per lane: joint, parent lane, anc[kMaxRounds], subtree size, depth
-// LDS image of the prior: rim rows 64..68 over columns 0..63 as [10][64 lanes][4] (lane 8m + s holds
-// columns 8s..8s+7 of the five rows of component m: float4 2c and 2c+1 for row 64+c), then mu | c = P mu
-// of rows 0..63 as [m][2][64]
+// LDS image of the prior: rim rows 64..68 over columns 0..63 as [m][5][64], then mu | c = P mu of rows 0..63 as [m][2][64]
 constexpr int kPriorRimFragEntries = 4 * 21;   // per component: 4 fragments [k-step 2][hi | lo] of 20 live lanes + one zero entry, 16 B each
 constexpr int kPriorImageFloats = 2 * 5 * 64 * 4 + kPriorMaxGauss * 2 * 64 + kPriorMaxGauss * kPriorRimFragEntries * 4;
 // the 64 x 64 core of every component as MFMA A fragments (f16 hi / lo, see k2b_api.hip):

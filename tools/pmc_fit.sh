@@ -1,7 +1,7 @@
 #!/bin/bash
-# PMC passes over the fit kernel (run on the GPU box): tools/pmc_fit.sh TAG FRAMES
+# PMC passes over the fit kernel (run on the GPU box): tools/pmc_fit.sh TAG FRAMES [debug_launch_shape]
 set -e
-TAG=$1; FR=$2
+TAG=$1; FR=$2; SHAPE=${3:-0}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/dev_fit_once.py $FR > $OUT.p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT.p$i.log; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/dev_fit_once.py $FR - 3 - $SHAPE > $OUT.p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT.p$i.log; }
 done
 python3 - <<PY
 import csv, glob, collections, json
