@@ -31,7 +31,7 @@ def _problem(B, seed=21, scale=0.8):
     return j3d, (go * scale, bp * scale, be * 0.5, tr + 0.02)
 
 
-def _host_twin(cfg, j3d, init, max_iter, lr=1e-2):
+def _host_twin(cfg, j3d, init, max_iter, lr=1e-2, history_size=100):
     """``BatchedLBFGS`` (numpy, float32 vectors) driving the same evaluate-only launches."""
     from keypoints2body_amd.core.lbfgs_batched import BatchedLBFGS
     m, pr = H.native_model(), H.native_prior()
@@ -49,7 +49,7 @@ def _host_twin(cfg, j3d, init, max_iter, lr=1e-2):
                              xt[:, 3 + D:3 + D + NB].contiguous(), xt[:, 3 + D + NB:].contiguous(), preserve_pose=preserve, want_grad=True)
         return r["loss"].cpu().numpy().astype(np.float64), r["grad"].cpu().numpy()
 
-    opt = BatchedLBFGS(evaluate, torch.cat(init, dim=1).cpu().numpy(), lr=lr, max_iter=max_iter)
+    opt = BatchedLBFGS(evaluate, torch.cat(init, dim=1).cpu().numpy(), lr=lr, max_iter=max_iter, history_size=history_size)
     return opt.run(), opt.rounds
 
 
@@ -143,3 +143,38 @@ def test_smplx_device_lbfgs_runs_the_tree_kernel_as_its_closure():
     start = native.fit_world(m, pr, cfg, list(range(55)), j3d, None, z(3), z(162), z(20), tr0)
     out = native.fit_world_lbfgs(m, pr, cfg, list(range(55)), j3d, None, z(3), z(162), z(20), tr0, max_iter=20, lr=1e-2)
     assert torch.isfinite(out["body_pose"]).all() and (out["loss"] < 0.6 * start["loss"]).all()
+
+
+def test_device_lbfgs_history_ring_drops_the_oldest_pair_like_torch():
+    """history_size smaller than the iteration count: torch pops the oldest (s, y) pair; the device keeps a ring.  Against the
+    CPU twin with the same limit, frame by frame (and against an unlimited history, which must differ - the limit is really
+    exercised).  A line search branches on rounding, so a frame either stays with its twin to ~1e-7 or leaves it by ~1e-3 at some
+    iteration (tools/dev_lbfgs_diag.py: with an UNLIMITED history two of six frames have left by iteration 8, with this limit none
+    by iteration 10): the gate is on the median frame."""
+    B, it = 6, 10
+    j3d, init = _problem(B, seed=13)
+    cfg = native.default_fit_config()
+    run = lambda h: native.fit_world_lbfgs(H.native_model(), H.native_prior(), cfg, list(range(22)), j3d, None, *init, max_iter=it, lr=1e-2,
+                                           history_size=h)
+    cat = lambda o: torch.cat([o[k] for k in ("global_orient", "body_pose", "betas", "transl")], dim=1).cpu().numpy()
+    small, full = cat(run(2)), cat(run(100))
+    twin, _ = _host_twin(cfg, j3d, init, it, history_size=2)
+    per_frame = np.abs(small - twin).max(axis=1)
+    print(f"history 2 against unlimited: {np.abs(small - full).max():.2e}; device - twin per frame {per_frame}")
+    assert np.abs(small - full).max() > 1e-6
+    assert np.median(per_frame) < 1e-5, per_frame
+
+
+def test_device_lbfgs_empty_batch_and_argument_checks():
+    m, pr = H.native_model(), H.native_prior()
+    cfg = native.default_fit_config()
+    e = lambda c: torch.zeros(0, c, device="cuda")
+    out = native.fit_world_lbfgs(m, pr, cfg, list(range(22)), torch.zeros(0, 22, 3, device="cuda"), None, e(3), e(69), e(10), e(3), max_iter=5, lr=1e-2)
+    assert out["body_pose"].shape == (0, 69)
+    j3d, init = _problem(2)
+    with pytest.raises(ValueError):
+        native.fit_world_lbfgs(m, pr, cfg, list(range(22)), j3d, None, *init, max_iter=0, lr=1e-2)
+    with pytest.raises(ValueError):
+        native.fit_world_lbfgs(m, pr, cfg, list(range(22)), j3d, None, *init, max_iter=5, lr=0.0)
+    with pytest.raises(NotImplementedError):
+        native.fit_world_lbfgs(m, pr, cfg, list(range(22)), j3d, None, *init, max_iter=5, lr=1e-2, history_size=101)
