@@ -227,6 +227,27 @@ int k2b_fit_world_lbfgs(const k2b_model *model, const k2b_prior *prior, const k2
                         double tolerance_change, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * k2b_fit_sequence_lbfgs — the reference's DEFAULT sequence mode in one call: the frame loop of
+ * `optimize_params_sequence` with `use_previous_frame_init=True` (api/sequence.py:214-281, config.py:57) over the L-BFGS
+ * branch (`use_lbfgs=True`, config.py:29; world_space.py:231-247).  ONE sequence of num_frames frames: frame 0 is fitted from
+ * the given start (*_in: one row) with first_iters iterations and no preserve term (world_space.py:159,211); every later frame
+ * starts from its predecessor's RESULT, preserves that result's body pose with cfg->pose_preserve_weight and runs
+ * followup_iters iterations (world_space.py:214).  Every frame is one k2b_fit_world_lbfgs fit; the call only queues launches
+ * (no host work between the frames).
+ *   j3d dev [T][K][3]; conf dev [K], or [T][K] with cfg->conf_per_frame (each frame reads its own row, as the sequence API
+ *   passes `conf[idx]`); *_out dev [T][...], loss_out dev [T] (may be NULL): every frame's result / loss at the result.
+ * cfg->transl_prior_weight must be 0.
+ * ------------------------------------------------------------------------------- */
+int k2b_fit_sequence_lbfgs(const k2b_model *model, const k2b_prior *prior, const k2b_fit_config *cfg,
+                           int32_t num_frames, int32_t num_targets, const int32_t *model_joint_index,
+                           const float *j3d, const float *conf,
+                           const float *global_orient_in, const float *body_pose_in, const float *betas_in,
+                           const float *transl_in,
+                           float *global_orient_out, float *body_pose_out, float *betas_out, float *transl_out,
+                           float *loss_out, int32_t first_iters, int32_t followup_iters, int32_t history_size,
+                           double lr, double tolerance_grad, double tolerance_change, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * k2b_lbs — full SMPL forward.  Replaces `self.smpl(**kwargs)` (smplx `SMPL.forward`,
  * call sites world_space.py:34,192,278; engine.py:114) for a batch:
  *   joints_out dev [B][J+E][3], vertices_out dev [B][V][3] (NULL: joints only; the E

@@ -180,10 +180,11 @@ class WorldSpaceFitter:
         return out, joints, verts, out["loss"]
 
     def chain_supported(self, target_model_indices=None) -> bool:
-        """Whether ``fit_chain`` can run this fitter's sequence mode in one launch: Adam branch, kinematic targets only
-        (otherwise the caller fits frame by frame)."""
+        """Whether ``fit_chain`` can run this fitter's sequence mode in one call: the Adam branch with kinematic targets (ONE
+        launch, ``k2b_fit_sequence``), or the L-BFGS branch on the device driver (``k2b_fit_sequence_lbfgs``: one device-driven
+        fit per frame, no host work between the frames); otherwise the caller fits frame by frame."""
         if self.use_lbfgs:
-            return False
+            return getattr(self, "lbfgs_driver", "device") == "device" and (self.smpl_index is not None or target_model_indices is not None)
         idx = self.smpl_index if target_model_indices is None else torch.as_tensor(target_model_indices).reshape(-1).tolist()
         return idx is not None and all(int(i) < self.smpl.num_joints for i in idx)
 
@@ -196,7 +197,7 @@ class WorldSpaceFitter:
         ``num_iters_followup`` iterations.  ``conf_3d``: (K,) or per frame (T, K) as the sequence API passes it.
         Returns ``(params: dict of (T,.) tensors, joints, vertices, per_frame_loss)`` like ``fit_batch``."""
         if not self.chain_supported(target_model_indices):
-            raise NotImplementedError("fit_chain: Adam branch and kinematic targets only")
+            raise NotImplementedError("fit_chain: the Adam branch with kinematic targets, or the L-BFGS branch on the device driver")
         per_frame = conf_3d is not None and torch.as_tensor(conf_3d).dim() == 2
         go, bp, be, tr, model_idx, tgt, conf = self._prepare(init_params, j3d, conf_3d, target_model_indices, per_frame,
                                                              num_init=1)
@@ -205,10 +206,15 @@ class WorldSpaceFitter:
         if self.smpl.packed:
             cfg.prior_pose_dims, cfg.num_betas_prior = 3 * self.smpl.NUM_BODY_JOINTS, self.smpl.num_betas
         T = tgt.shape[0]
-        out = native.fit_sequence(self.smpl.native, self.pose_prior.native, cfg, int(self.num_iters_followup), model_idx,
-                                  tgt.unsqueeze(0), None if conf is None else (conf.unsqueeze(0) if per_frame else conf),
-                                  go, bp, be, tr)
-        out = {k: v.reshape((T,) + tuple(v.shape[2:])) for k, v in out.items()}
+        if self.use_lbfgs:
+            cfg.freeze_betas = int(bool(freeze_betas))
+            out = native.fit_sequence_lbfgs(self.smpl.native, self.pose_prior.native, cfg, int(self.num_iters_first),
+                                            int(self.num_iters_followup), model_idx, tgt, conf, go, bp, be, tr, lr=float(self.step_size))
+        else:
+            out = native.fit_sequence(self.smpl.native, self.pose_prior.native, cfg, int(self.num_iters_followup), model_idx,
+                                      tgt.unsqueeze(0), None if conf is None else (conf.unsqueeze(0) if per_frame else conf),
+                                      go, bp, be, tr)
+            out = {k: v.reshape((T,) + tuple(v.shape[2:])) for k, v in out.items()}
         if not run_forward:
             return out, None, None, out["loss"]
         joints, verts = self.final_forward(out, want_vertices=want_vertices)

@@ -973,6 +973,61 @@ int k2b_fit_sequence(const k2b_model* model, const k2b_prior* prior, const k2b_f
                           go_out, bp_out, be_out, tr_out, loss_out, nullptr, stream, frames_per_sequence, followup_iters);
 }
 
+namespace {
+// One device-driven L-BFGS fit of B frames whose start is ALREADY in the parameter arrays (go, bp, be, tr: in place): state
+// cleared, max_eval + 2 rounds of [closure, step], finalise, loss (+ gradient) at the result.  `ws` = lbfgs_ws_bytes() of
+// stream-ordered scratch, `pres` / `trp` = preserve pose / translation prior centre (device, outside the parameter arrays).
+struct LbfgsWs { unsigned char* base; size_t off_si, off_sv, n_state; float *gbuf, *lbuf; };
+size_t lbfgs_ws_layout(int B, int P, int H, LbfgsWs* w) {
+    w->n_state = k2b::lbfgs_state_bytes(B, P, H, &w->off_si, &w->off_sv);
+    return w->n_state + ((size_t)B * P + B) * sizeof(float);
+}
+int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
+              const int32_t* model_joint_index, const float* j3d, const float* conf, const float* pres, const float* trp,
+              float* go, float* bp, float* be, float* tr, float* loss_out, float* grad_out, int max_iter, int H, double lr,
+              double tol_g, double tol_c, const LbfgsWs& w, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int NB = model_c->NB, D = 3 * (model_c->J - 1), P = 3 + D + NB + 3;
+    const int max_eval = max_iter * 5 / 4;                               // torch's default
+    HIP_TRY(hipMemsetAsync(w.base, 0, w.off_sv, stream));               // scalars and integers: phase INIT (vectors are written before they are read)
+    k2b_fit_config ec = *cfg;
+    ec.num_iters = 1;
+    ec.step_size = 0.0;                                                  // evaluate-only: the closure
+    auto closure = [&](float* loss, float* grad) {
+        return fit_world_impl(model_c, prior, &ec, B, K, model_joint_index, j3d, conf, go, bp, be, tr, pres, trp,
+                              go, bp, be, tr, loss, grad, stream_v, 1, 0);
+    };
+    k2b::LbfgsArgs la{};
+    la.B = B; la.P = P; la.D = D; la.NB = NB; la.H = H;
+    la.max_iter = max_iter; la.max_eval = max_eval;
+    la.lr = lr; la.tol_g = tol_g; la.tol_c = tol_c;
+    la.go = go; la.bp = bp; la.be = be; la.tr = tr;
+    la.loss_in = w.lbuf; la.grad_in = w.gbuf;
+    la.sd = reinterpret_cast<double*>(w.base); la.si = reinterpret_cast<int*>(w.base + w.off_si); la.sv = reinterpret_cast<float*>(w.base + w.off_sv);
+    const int rounds = max_eval + 2;
+    for (int r = 0; r < rounds; ++r) {
+        if (const int rc = closure(w.lbuf, w.gbuf); rc != K2B_OK) return rc;
+        HIP_TRY(k2b::launch_lbfgs_step(la, stream));
+    }
+    la.finalize = 1;
+    HIP_TRY(k2b::launch_lbfgs_step(la, stream));
+    // loss (and gradient) at the result (world_space.py:245-246 evaluates the loss once more behind the optimiser)
+    return closure(loss_out ? loss_out : w.lbuf, grad_out);
+}
+int lbfgs_check(const k2b_model* model, const k2b_prior* prior, const k2b_fit_config* cfg, int max_iter, int* history_size, double lr,
+                const char* who) {
+    if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "%s: model, prior and cfg are required", who);
+    if (max_iter < 1 || max_iter > 10000) return fail(K2B_ERR_INVALID_ARGUMENT, "%s: max_iter=%d", who, max_iter);
+    if (*history_size <= 0) *history_size = k2b::kLbfgsMaxHistory;
+    if (*history_size > k2b::kLbfgsMaxHistory)
+        return fail(K2B_ERR_UNSUPPORTED, "%s: history_size=%d (at most %d)", who, *history_size, k2b::kLbfgsMaxHistory);
+    if (!(lr > 0.0)) return fail(K2B_ERR_INVALID_ARGUMENT, "%s: lr must be positive", who);
+    if (3 + 3 * (model->J - 1) + model->NB + 3 > 192)
+        return fail(K2B_ERR_UNSUPPORTED, "%s: %d parameters per frame (at most 192)", who, 3 + 3 * (model->J - 1) + model->NB + 3);
+    return K2B_OK;
+}
+}  // namespace
+
 // L-BFGS branch of the fitters on the device (world_space.py:231-247, camera_space.py:144-182,229-267): per frame
 // torch.optim.LBFGS(max_iter, lr, line_search_fn="strong_wolfe").step(closure), the closure = this library's evaluate-only fit
 // launch, the optimiser = k2b_lbfgs.hip's state machine.  Only launches are queued: max_eval + 2 rounds of [closure, step], then
@@ -983,63 +1038,89 @@ int k2b_fit_world_lbfgs(const k2b_model* model_c, const k2b_prior* prior, const 
                         float* go_out, float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out,
                         int32_t max_iter, int32_t history_size, double lr, double tolerance_grad, double tolerance_change,
                         void* stream_v) {
-    k2b_model* model = const_cast<k2b_model*>(model_c);
-    if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: model, prior and cfg are required");
+    if (const int rc = lbfgs_check(model_c, prior, cfg, max_iter, &history_size, lr, "k2b_fit_world_lbfgs"); rc != K2B_OK) return rc;
     if (B < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: num_frames=%d", B);
-    if (max_iter < 1 || max_iter > 10000) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: max_iter=%d", max_iter);
-    if (history_size <= 0) history_size = k2b::kLbfgsMaxHistory;
-    if (history_size > k2b::kLbfgsMaxHistory) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world_lbfgs: history_size=%d (at most %d)", history_size, k2b::kLbfgsMaxHistory);
-    if (!(lr > 0.0)) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: lr must be positive");
     if (B == 0) return K2B_OK;
     if (!go_in || !bp_in || !be_in || !tr_in || !go_out || !bp_out || !be_out || !tr_out)
         return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world_lbfgs: NULL parameter buffer");
     hipStream_t stream = (hipStream_t)stream_v;
-    const int NB = model->NB, D = 3 * (model->J - 1), P = 3 + D + NB + 3;
-    if (P > 192) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world_lbfgs: %d parameters per frame (at most 192)", P);
+    const int NB = model_c->NB, D = 3 * (model_c->J - 1), P = 3 + D + NB + 3;
     const int H = history_size < max_iter ? history_size : max_iter;      // (a fit makes at most max_iter - 1 pairs)
-    const int max_eval = max_iter * 5 / 4;                               // torch's default
     // stream-ordered workspace: optimiser state, closure results, the preserve pose and the translation prior's centre (their
     // defaults are the INITIAL parameters, which the parameter arrays stop holding after the first step)
-    size_t off_si = 0, off_sv = 0;
-    const size_t n_state = k2b::lbfgs_state_bytes(B, P, H, &off_si, &off_sv);
-    const size_t n_f = (size_t)B * P + B + (size_t)B * D + (size_t)B * 3;
+    LbfgsWs w{};
+    const size_t n_opt = lbfgs_ws_layout(B, P, H, &w);
     unsigned char* ws = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&ws, n_state + n_f * sizeof(float), stream));
+    HIP_TRY(hipMallocAsync((void**)&ws, n_opt + ((size_t)B * D + (size_t)B * 3) * sizeof(float), stream));
     auto cleanup = [&](int rc) { (void)hipFreeAsync(ws, stream); return rc; };
 #define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_world_lbfgs: HIP call failed")); } } while (0)
-    float* gbuf = reinterpret_cast<float*>(ws + n_state);
-    float *lbuf = gbuf + (size_t)B * P, *pres = lbuf + B, *trp = pres + (size_t)B * D;
-    K2B_TRY_WS(hipMemsetAsync(ws, 0, off_sv, stream));                  // scalars and integers: phase INIT (vectors are written before they are read)
+    w.base = ws;
+    w.gbuf = reinterpret_cast<float*>(ws + w.n_state);
+    w.lbuf = w.gbuf + (size_t)B * P;
+    float *pres = w.lbuf + B, *trp = pres + (size_t)B * D;
     K2B_TRY_WS(hipMemcpyAsync(pres, preserve ? preserve : bp_in, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
     K2B_TRY_WS(hipMemcpyAsync(trp, tr_prior ? tr_prior : tr_in, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     const struct { const float* src; float* dst; size_t n; } cp[] = {
         {go_in, go_out, (size_t)B * 3}, {bp_in, bp_out, (size_t)B * D}, {be_in, be_out, (size_t)B * NB}, {tr_in, tr_out, (size_t)B * 3}};
     for (const auto& c : cp)
         if (c.src != c.dst) K2B_TRY_WS(hipMemcpyAsync(c.dst, c.src, c.n * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    k2b_fit_config ec = *cfg;
-    ec.num_iters = 1;
-    ec.step_size = 0.0;                                                  // evaluate-only: the closure
-    auto closure = [&](float* loss, float* grad) {
-        return fit_world_impl(model_c, prior, &ec, B, K, model_joint_index, j3d, conf, go_out, bp_out, be_out, tr_out, pres,
-                              (tr_prior || cfg->transl_prior_weight != 0.0f) ? trp : nullptr,   // (the tree kernel has no translation prior)
-                              go_out, bp_out, be_out, tr_out, loss, grad, stream_v, 1, 0);
-    };
-    k2b::LbfgsArgs la{};
-    la.B = B; la.P = P; la.D = D; la.NB = NB; la.H = H;
-    la.max_iter = max_iter; la.max_eval = max_eval;
-    la.lr = lr; la.tol_g = tolerance_grad; la.tol_c = tolerance_change;
-    la.go = go_out; la.bp = bp_out; la.be = be_out; la.tr = tr_out;
-    la.loss_in = lbuf; la.grad_in = gbuf;
-    la.sd = reinterpret_cast<double*>(ws); la.si = reinterpret_cast<int*>(ws + off_si); la.sv = reinterpret_cast<float*>(ws + off_sv);
-    const int rounds = max_eval + 2;
-    for (int r = 0; r < rounds; ++r) {
-        if (const int rc = closure(lbuf, gbuf); rc != K2B_OK) return cleanup(rc);
-        K2B_TRY_WS(k2b::launch_lbfgs_step(la, stream));
+#undef K2B_TRY_WS
+    return cleanup(lbfgs_run(model_c, prior, cfg, B, K, model_joint_index, j3d, conf, pres,
+                             (tr_prior || cfg->transl_prior_weight != 0.0f) ? trp : nullptr,   // (the tree kernel has no translation prior)
+                             go_out, bp_out, be_out, tr_out, loss_out, grad_out, max_iter, H, lr, tolerance_grad, tolerance_change, w, stream_v));
+}
+
+// The reference's DEFAULT sequence mode in one call: the frame loop of optimize_params_sequence with use_previous_frame_init=True
+// (api/sequence.py:214-281) over the L-BFGS branch (world_space.py:231-247).  Frame 0 is fitted from the given start with
+// first_iters iterations and no preserve term; every later frame starts from its predecessor's RESULT, preserves that result's
+// body pose with cfg->pose_preserve_weight (world_space.py:159,211) and runs followup_iters iterations; each frame is one
+// device-driven L-BFGS fit (k2b_fit_world_lbfgs) and only launches are queued - no host work between the frames.
+int k2b_fit_sequence_lbfgs(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t T, int32_t K,
+                           const int32_t* model_joint_index, const float* j3d, const float* conf, const float* go_in,
+                           const float* bp_in, const float* be_in, const float* tr_in, float* go_out, float* bp_out, float* be_out,
+                           float* tr_out, float* loss_out, int32_t first_iters, int32_t followup_iters, int32_t history_size, double lr,
+                           double tolerance_grad, double tolerance_change, void* stream_v) {
+    if (const int rc = lbfgs_check(model_c, prior, cfg, first_iters, &history_size, lr, "k2b_fit_sequence_lbfgs"); rc != K2B_OK) return rc;
+    if (followup_iters < 1 || followup_iters > 10000) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_sequence_lbfgs: followup_iters=%d", followup_iters);
+    if (T < 0) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_sequence_lbfgs: frames=%d", T);
+    if (cfg->transl_prior_weight != 0.0f) return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_sequence_lbfgs: no translation prior in a chain");
+    if (T == 0) return K2B_OK;
+    if (!j3d || !go_in || !bp_in || !be_in || !tr_in || !go_out || !bp_out || !be_out || !tr_out)
+        return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_sequence_lbfgs: NULL parameter / target buffer");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int NB = model_c->NB, D = 3 * (model_c->J - 1), P = 3 + D + NB + 3;
+    const int it_max = first_iters > followup_iters ? first_iters : followup_iters;
+    const int Hmax = history_size < it_max ? history_size : it_max;
+    LbfgsWs w{};
+    const size_t n_opt = lbfgs_ws_layout(1, P, Hmax, &w);
+    unsigned char* ws = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&ws, n_opt + (size_t)D * sizeof(float), stream));
+    auto cleanup = [&](int rc) { (void)hipFreeAsync(ws, stream); return rc; };
+#define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_sequence_lbfgs: HIP call failed")); } } while (0)
+    w.base = ws;
+    w.gbuf = reinterpret_cast<float*>(ws + w.n_state);
+    w.lbuf = w.gbuf + P;
+    float* pres = w.lbuf + 1;
+    k2b_fit_config fc = *cfg;
+    for (int t = 0; t < T; ++t) {
+        float *go = go_out + (size_t)t * 3, *bp = bp_out + (size_t)t * D, *be = be_out + (size_t)t * NB, *tr = tr_out + (size_t)t * 3;
+        const float *sgo = t ? go - 3 : go_in, *sbp = t ? bp - D : bp_in, *sbe = t ? be - NB : be_in, *str = t ? tr - 3 : tr_in;
+        // start of this frame = the start given (frame 0) or the previous frame's result; its body pose is also what is preserved
+        K2B_TRY_WS(hipMemcpyAsync(go, sgo, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        K2B_TRY_WS(hipMemcpyAsync(bp, sbp, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        K2B_TRY_WS(hipMemcpyAsync(be, sbe, (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        K2B_TRY_WS(hipMemcpyAsync(tr, str, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        K2B_TRY_WS(hipMemcpyAsync(pres, sbp, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        fc.pose_preserve_weight = t ? cfg->pose_preserve_weight : 0.0f;
+        const int iters = t ? followup_iters : first_iters;
+        const int H = history_size < iters ? history_size : iters;
+        const float* cf = conf ? conf + (cfg->conf_per_frame ? (size_t)t * K : 0) : nullptr;
+        k2b_fit_config one = fc;
+        one.conf_per_frame = 0;                                   // (one frame per fit: its row of a per-frame array is a shared row)
+        if (const int rc = lbfgs_run(model_c, prior, &one, 1, K, model_joint_index, j3d + (size_t)t * K * 3, cf, pres, nullptr, go, bp, be, tr,
+                                     loss_out ? loss_out + t : nullptr, nullptr, iters, H, lr, tolerance_grad, tolerance_change, w, stream_v);
+            rc != K2B_OK) return cleanup(rc);
     }
-    la.finalize = 1;
-    K2B_TRY_WS(k2b::launch_lbfgs_step(la, stream));
-    // loss (and gradient) at the result (world_space.py:245-246 evaluates the loss once more behind the optimiser)
-    if (const int rc = closure(loss_out ? loss_out : lbuf, grad_out); rc != K2B_OK) return cleanup(rc);
 #undef K2B_TRY_WS
     return cleanup(K2B_OK);
 }

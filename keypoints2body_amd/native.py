@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "k2b_version", "k2b_last_error", "k2b_model_create", "k2b_model_destroy", "k2b_model_dims",
     "k2b_model_joint_basis", "k2b_model_reserve", "k2b_debug_read_dump", "k2b_prior_create", "k2b_prior_destroy", "k2b_fit_config_default", "k2b_fit_config_size",
     "k2b_fit_world", "k2b_fit_sequence", "k2b_lbs", "k2b_vertex_term", "k2b_adam_step", "k2b_angular_error_deg",
-    "k2b_fit_world_lbfgs",
+    "k2b_fit_world_lbfgs", "k2b_fit_sequence_lbfgs",
 )
 
 
@@ -108,6 +108,9 @@ def load_library():
     lib.k2b_fit_world_lbfgs.restype = C.c_int
     lib.k2b_fit_world_lbfgs.argtypes = ([vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 14 +
                                         [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, vp])
+    lib.k2b_fit_sequence_lbfgs.restype = C.c_int
+    lib.k2b_fit_sequence_lbfgs.argtypes = ([vp, vp, C.POINTER(FitConfigC), C.c_int32, C.c_int32, ip] + [fp] * 11 +
+                                           [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, vp])
     lib.k2b_vertex_term.restype = C.c_int
     lib.k2b_vertex_term.argtypes = [vp, C.c_int32, C.c_int32, ip, fp, fp, C.c_float, C.c_float] + [fp] * 6 + [vp]
     lib.k2b_adam_step.restype = C.c_int
@@ -359,6 +362,41 @@ def fit_world_lbfgs(model: NativeModel, prior: NativePrior, cfg: FitConfigC, mod
             C.c_void_p(out["loss"].data_ptr()), C.c_void_p(out["grad"].data_ptr()) if want_grad else None,
             int(max_iter), int(history_size), float(lr), float(tolerance_grad), float(tolerance_change), stream),
             "k2b_fit_world_lbfgs")
+    return out
+
+
+def fit_sequence_lbfgs(model: NativeModel, prior: NativePrior, cfg: FitConfigC, first_iters: int, followup_iters: int,
+                       model_joint_index: Sequence[int], j3d: torch.Tensor, conf: Optional[torch.Tensor],
+                       global_orient: torch.Tensor, body_pose: torch.Tensor, betas: torch.Tensor, transl: torch.Tensor, *, lr: float,
+                       history_size: int = 100, tolerance_grad: float = 1e-7, tolerance_change: float = 1e-9):
+    """ONE warm-start sequence under the L-BFGS branch (``k2b_fit_sequence_lbfgs``): ``j3d`` (T, K, 3), start (1, ...) of frame
+    0; every later frame starts from its predecessor's result with ``cfg.pose_preserve_weight``; returns (T, ...) tensors."""
+    dev = model.device
+    T, K = j3d.shape[0], j3d.shape[1]
+    D = 3 * (model.num_joints - 1)
+    idx = _host_i32(np.asarray(list(model_joint_index)))
+    if idx.shape != (K,):
+        raise ValueError(f"model_joint_index has {idx.shape[0]} entries for {K} targets")
+    conf_p = None
+    if conf is not None:
+        conf_p = _dev(conf, "conf", dev, (T, K) if cfg.conf_per_frame else (K,))
+    out = {
+        "global_orient": torch.empty((T, 3), dtype=torch.float32, device=dev),
+        "body_pose": torch.empty((T, D), dtype=torch.float32, device=dev),
+        "betas": torch.empty((T, model.num_betas), dtype=torch.float32, device=dev),
+        "transl": torch.empty((T, 3), dtype=torch.float32, device=dev),
+        "loss": torch.empty((T,), dtype=torch.float32, device=dev),
+    }
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _check(load_library().k2b_fit_sequence_lbfgs(
+            model.handle, prior.handle, C.byref(cfg), T, K, _np_ptr(idx), _dev(j3d, "j3d", dev, (T, K, 3)), conf_p,
+            _dev(global_orient, "global_orient", dev, (1, 3)), _dev(body_pose, "body_pose", dev, (1, D)),
+            _dev(betas, "betas", dev, (1, model.num_betas)), _dev(transl, "transl", dev, (1, 3)),
+            C.c_void_p(out["global_orient"].data_ptr()), C.c_void_p(out["body_pose"].data_ptr()),
+            C.c_void_p(out["betas"].data_ptr()), C.c_void_p(out["transl"].data_ptr()), C.c_void_p(out["loss"].data_ptr()),
+            int(first_iters), int(followup_iters), int(history_size), float(lr), float(tolerance_grad), float(tolerance_change),
+            stream), "k2b_fit_sequence_lbfgs")
     return out
 
 

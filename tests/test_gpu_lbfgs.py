@@ -178,3 +178,52 @@ def test_device_lbfgs_empty_batch_and_argument_checks():
         native.fit_world_lbfgs(m, pr, cfg, list(range(22)), j3d, None, *init, max_iter=5, lr=0.0)
     with pytest.raises(NotImplementedError):
         native.fit_world_lbfgs(m, pr, cfg, list(range(22)), j3d, None, *init, max_iter=5, lr=1e-2, history_size=101)
+
+
+def test_default_sequence_mode_in_one_call_equals_the_frame_loop():
+    """``k2b_fit_sequence_lbfgs`` (the reference's DEFAULT sequence mode: warm start + L-BFGS, api/sequence.py:214-281 over
+    world_space.py:231-247) against the same loop driven frame by frame through ``fit_frame`` - ``prev = res.params``, frame 0
+    with ``num_iters_first`` and no preserve term, the others with ``num_iters_followup`` and the preserve term - bit for bit;
+    per-frame confidences (``fix_foot``) included; and through the public ``optimize_params_sequence``."""
+    import keypoints2body_amd as k2b
+    from keypoints2body_amd.core.config import FrameOptimizeConfig, SequenceOptimizeConfig
+    from keypoints2body_amd.core.fitters.world_space import WorldSpaceFitter
+    from keypoints2body_amd.models.body_model import BodyModel
+    from keypoints2body_amd.prior import MaxMixturePrior, MixtureBuffers
+    g = H.gmm_fixture()
+    prior = MaxMixturePrior(MixtureBuffers(g["ref_means"], g["ref_precisions"], g["ref_nll_weights"].reshape(-1)))
+    model = BodyModel.synthetic(0)
+    T = 9
+    p = synthetic.make_poses(1, seed=17)
+    rng = np.random.default_rng(2)
+    walk = np.cumsum(0.03 * rng.standard_normal((T, 69)), axis=0).astype(np.float32)
+    with torch.no_grad():
+        j = H.oracle_model()(global_orient=torch.tensor(np.repeat(p.global_orient, T, 0)), body_pose=torch.tensor(p.body_pose + walk),
+                             betas=torch.tensor(np.repeat(p.betas, T, 0)), transl=torch.tensor(np.repeat(p.transl, T, 0))).joints[:, :22]
+    conf = torch.ones(T, 22)
+    conf[:, [7, 8, 10, 11]] = 1.5
+    fitter = WorldSpaceFitter(model, step_size=1e-2, num_iters_first=12, num_iters_followup=5, use_lbfgs=True, joints_category="AMASS",
+                              pose_prior=prior)
+    z = lambda c: torch.zeros(1, c)
+    start = k2b.SMPLData(betas=z(10), global_orient=z(3), body_pose=z(69), transl=j[:1, 0].clone())
+    assert fitter.chain_supported(None)
+    out, joints, verts, loss = fitter.fit_chain(start, j, conf)
+    prev = start
+    for t in range(T):
+        res = fitter.fit_frame(prev, j[t:t + 1], conf_3d=conf[t], seq_ind=t)
+        for k in ("global_orient", "body_pose", "betas", "transl"):
+            assert torch.equal(out[k][t:t + 1], getattr(res.params, k)), (t, k)
+        assert torch.equal(joints[t:t + 1], res.joints) and float(loss[t]) == float(res.loss)
+        prev = res.params
+    # the public API takes this path for the reference's default configuration
+    cfg = SequenceOptimizeConfig(frame=FrameOptimizeConfig(num_iters_first=12, num_iters_followup=5, joints_category="AMASS"),
+                                 use_shape_optimization=False, fix_foot=True)
+    assert cfg.frame.use_lbfgs and cfg.use_previous_frame_init
+    seq = np.concatenate([j.numpy(), np.ones((T, 22, 1), np.float32)], axis=2)
+    api = k2b.optimize_params_sequence(seq, init_params=start, joint_layout="AMASS", model=model, config=cfg, pose_prior=prior,
+                                       mean_params=(torch.zeros(1, 72), torch.zeros(1, 10)))
+    assert len(api) == T
+    ref, _, _, _ = fitter.fit_chain(start, j, conf, joint_loss_weight=cfg.frame.joint_loss_weight,
+                                    pose_preserve_weight=cfg.frame.pose_preserve_weight, freeze_betas=cfg.frame.freeze_betas)
+    for t in (0, 1, T - 1):
+        assert torch.equal(api[t].params.body_pose, ref["body_pose"][t:t + 1]) and torch.equal(api[t].params.betas, ref["betas"][t:t + 1])
