@@ -618,9 +618,11 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         // round trip), then ONE round of cross-lane fetches for the range ends.
         float sums[6];
         {
+            // (lanes beyond the tree carry no target: wconf = 0 there, so g and p x g are exact zeros without a select - their
+            //  transforms are identities over zero offsets, every factor is finite)
             const Vec3 pxg = cross(pj, gj);
-            const float lo[3] = {isJ ? gj.x : 0.f, isJ ? gj.y : 0.f, isJ ? gj.z : 0.f};
-            const float hi[3] = {isJ ? pxg.x : 0.f, isJ ? pxg.y : 0.f, isJ ? pxg.z : 0.f};
+            const float lo[3] = {gj.x, gj.y, gj.z};
+            const float hi[3] = {pxg.x, pxg.y, pxg.z};
             if (PAIR) {
                 // both halves carry a tree: six scans
 #pragma unroll
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                     const double scan = half_wave_inclusive_scan(v);
                     const double hi_end = bperm64(sub_end_addr, scan);  // prefix at the last lane of the subtree
                     const double lo_end = scan - (double)v;             // prefix just before its first lane (this lane)
-                    sums[i] = sub_ok ? (float)(hi_end - lo_end) : 0.f;
+                    sums[i] = (float)(hi_end - lo_end);                 // (lanes beyond the tree: window = the lane itself, an exact zero)
                 }
             } else {
                 // the two triples ride in the two 32-lane halves (g in lanes t, p x g in lanes 32 + t): three scans
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                     const double scan = half_wave_inclusive_scan(w3[i]);
                     const double hi_end = bperm64(sub_end_addr, scan);
                     const double lo_end = scan - (double)w3[i];
-                    s3[i] = sub_ok ? (float)(hi_end - lo_end) : 0.f;
+                    s3[i] = (float)(hi_end - lo_end);
                 }
                 // bring the p x g sums back to the joint's own lane
 #pragma unroll
@@ -680,10 +682,11 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         {
             float dd[4 * DDQ];
             read_dd(dd);
+            const Vec3 gz = {isJ ? gd.x : 0.f, isJ ? gd.y : 0.f, isJ ? gd.z : 0.f};     // one select per component instead of one per beta
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int kk = k < NBT ? k : 0;
-                gb[k] = (isJ && k < NBT) ? gd.x * dd[kk] + gd.y * dd[NBT + kk] + gd.z * dd[2 * NBT + kk] : 0.f;
+                gb[k] = k < NBT ? gz.x * dd[kk] + gz.y * dd[NBT + kk] + gz.z * dd[2 * NBT + kk] : 0.f;
             }
         }
         // d joint-loss / d beta_k summed over the tree; which lane ends up with which k: see the helpers
