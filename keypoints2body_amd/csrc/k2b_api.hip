@@ -84,6 +84,7 @@ struct k2b_model {
     } mesh, extra;
     bool joints_in_mesh = false;                             // every extra joint's vertex is tagged in mesh.w2 (no gather launch)
     bool stream = false;                                     // 17-24 joints and 7 pose k-steps: the stream kernel skins this model
+    bool stream_x = false;                                   // 49-56 joints and 16 pose k-steps (SMPL-X): k2b_lbs_stream_x_kernel
     // tables of the tree fit kernel (any J <= 64), lane order = DFS pre-order
     float *tt_dt = nullptr, *tt_dd = nullptr;
     int *tt_tab = nullptr, *tt_anc = nullptr;
@@ -191,6 +192,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         m->k_steps_x = KX;
         m->groups_a = k2b::tile_groups_a(J);
         m->stream = K2B_LBS_STREAM && m->groups_a == 3 && KX == 2 * k2b::kStreamKSteps;
+        m->stream_x = K2B_LBS_STREAM && m->groups_a == 7 && KX == 2 * k2b::kStreamXKSteps;
         HIP_TRY(hipMalloc((void**)&m->dump, 64 * 1024));     // 64 x 3 floats used; the rest is room for diagnostic builds
         // tag[i] = 1 + e when vertex i of the set is the vertex of output joint J + e (mesh set only), else 0
         auto build = [&](k2b_model::VertexSet& vs, const std::vector<int>& ids, const std::vector<int>& tag) -> int {
@@ -240,12 +242,12 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                     if (i < n && !tag.empty() && tag[i]) rowp[(size_t)(2 * GA + 1) * 128] = (k2b::k2b_half)(float)tag[i];   // ZERO group: joint tag
                 }
             hipError_t e;
-            if (m->stream) {
-                // stream kernel: Pd [k-step][16-vertex tile][coord][hi | lo] and W [16-vertex tile][3 fragments], 1 KiB pieces in
+            if (m->stream || m->stream_x) {
+                // stream kernels: Pd [k-step][16-vertex tile][coord][hi | lo] and W [16-vertex tile][3 or 5 fragments], 1 KiB pieces in
                 // MFMA operand order (lane = row + 16 k-group, 8 halfs); vertex tiles padded to whole 128-vertex groups
-                const int nv16 = (n + 127) / 128 * 8;
+                const int nv16 = (n + 127) / 128 * 8, SK = KX / 2, NWF = m->stream ? 3 : 5;
                 vs.nv16 = nv16;
-                std::vector<k2b::k2b_half> spd((size_t)k2b::kStreamKSteps * nv16 * 6 * 512, (k2b::k2b_half)0.f), sw((size_t)nv16 * 3 * 512, (k2b::k2b_half)0.f);
+                std::vector<k2b::k2b_half> spd((size_t)SK * nv16 * 6 * 512, (k2b::k2b_half)0.f), sw((size_t)nv16 * NWF * 512, (k2b::k2b_half)0.f);
                 for (int i = 0; i < n; ++i) {
                     const int v16 = i >> 4, r = i & 15;
                     for (int c = 0; c < 3; ++c)
@@ -255,15 +257,19 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                             spd[dst] = pdh[src];
                             spd[dst + 512] = pdl[src];
                         }
-                    k2b::k2b_half* wt = sw.data() + (size_t)v16 * 3 * 512;
+                    k2b::k2b_half* wt = sw.data() + (size_t)v16 * NWF * 512;
+                    auto at = [&](int frag, int group, int k) -> k2b::k2b_half& { return wt[(size_t)frag * 512 + (size_t)((group * 16 + r) * 8 + k)]; };
                     for (int j = 0; j < J; ++j) {
                         const float w = lbs_weights[(size_t)ids[i] * J + j];
-                        const k2b::k2b_half hi = (k2b::k2b_half)w;
-                        const size_t o = (size_t)(((j >> 3) * 16 + r) * 8 + (j & 7));
-                        wt[o] = hi; wt[512 + o] = hi; wt[1024 + o] = (k2b::k2b_half)(w - (float)hi);
+                        const k2b::k2b_half hi = (k2b::k2b_half)w, lo = (k2b::k2b_half)(w - (float)hi);
+                        const int gj = j >> 3, kj = j & 7;
+                        if (m->stream) { at(0, gj, kj) = hi; at(1, gj, kj) = hi; at(2, gj, kj) = lo; }
+                        else if (gj < 4) { at(0, gj, kj) = hi; at(2, gj, kj) = lo; }
+                        else { at(1, gj - 4, kj) = hi; at(4, gj - 4, kj) = hi; at(3, gj - 4, kj) = lo; }
                     }
-                    for (int k = 0; k < 3; ++k) wt[(size_t)((3 * 16 + r) * 8 + k)] = (k2b::k2b_half)1.f;          // fragment 0, group 3: ONES
-                    if (!tag.empty() && tag[i]) wt[512 + (size_t)((3 * 16 + r) * 8)] = (k2b::k2b_half)(float)tag[i];   // fragment 1, group 3: tag
+                    // last group of the fragment that meets the PAD group of A: ONES; of the one that meets ZERO: the joint tag
+                    for (int k = 0; k < 3; ++k) at(m->stream ? 0 : 1, 3, k) = (k2b::k2b_half)1.f;
+                    if (!tag.empty() && tag[i]) at(m->stream ? 1 : 4, 3, 0) = (k2b::k2b_half)(float)tag[i];
                 }
                 if ((e = upload(&vs.spd, spd.data(), spd.size())) != hipSuccess) return (int)e;
                 if ((e = upload(&vs.sw, sw.data(), sw.size())) != hipSuccess) return (int)e;
@@ -1176,17 +1182,17 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
     if (m->groups_a != 3 && m->groups_a != 7)
         return fail(K2B_ERR_UNSUPPORTED, "k2b_lbs: %d joints; the vertex kernel is built for 17-24 (SMPL) and 49-56 (SMPL-H / SMPL-X) joints", m->J);
     pa.xh = m->wsXh; pa.xl = m->wsXl; pa.a2 = m->wsA2; pa.joints_out = joints_out;
-    pa.a2_stream_order = m->stream ? 1 : 0;
+    pa.a2_stream_order = (m->stream || m->stream_x) ? 1 : 0;
     HIP_TRY(k2b::launch_pose_setup(pa, stream));
     auto skin = [&](const k2b_model::VertexSet& vs, float* out, int stride, int row0, float* joint_copies) -> hipError_t {
-        if (m->stream) {
+        if (m->stream || m->stream_x) {
             k2b::StreamArgs sa{};
             sa.xh = m->wsXh; sa.xl = m->wsXl; sa.a2 = m->wsA2; sa.pd = vs.spd; sa.w = vs.sw;
             sa.f32_tiles = bpad / 32; sa.nv16 = vs.nv16;
             sa.num_frames = B; sa.num_out = vs.num; sa.out = out; sa.out_stride = stride; sa.out_row0 = row0;
             sa.dump = m->dump;
             sa.joints_out = joint_copies; sa.joints_stride = m->J + m->E; sa.joints_row0 = m->J;
-            return k2b::launch_skin_stream(sa, device_cus(), stream);
+            return m->stream ? k2b::launch_skin_stream(sa, device_cus(), stream) : k2b::launch_skin_stream_x(sa, device_cus(), stream);
         }
         k2b::TileArgs ta{};
         ta.xh = m->wsXh; ta.xl = m->wsXl; ta.a2 = m->wsA2; ta.pdh = vs.pdh; ta.pdl = vs.pdl; ta.w2 = vs.w2;

@@ -186,6 +186,12 @@ struct StreamArgs {
     int num_wgs;
 };
 hipError_t launch_skin_stream(const StreamArgs& a, int num_cus, hipStream_t stream);
+// 49-56 joints and 16 pose k-steps (SMPL-X), k2b_lbs_stream_x_kernel: the same operands with
+//   A   [16-frame tile][entry 12][fragment 4]: hi_0-3 | hi_4-6 PAD | lo_0-3 | lo_4-6 ZERO   (a2_stream_order with GA = 7)
+//   Pd  [k-step 16][16-vertex tile][coordinate 3][hi | lo]
+//   W   [16-vertex tile][5]: hi_0-3, [hi_4-6 | ONES], lo_0-3, [lo_4-6 | 0], [hi_4-6 | tag]
+constexpr int kStreamXKSteps = 16;
+hipError_t launch_skin_stream_x(const StreamArgs& a, int num_cus, hipStream_t stream);
 hipError_t launch_gather_joints(const float* verts, const int* ids, float* joints, int num_frames, int V, int J, int E,
                                 hipStream_t stream);
 

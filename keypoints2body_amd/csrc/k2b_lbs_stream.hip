@@ -48,6 +48,12 @@ constexpr int kUnitBytes = 24 * 1024;              // A operand of one 16-frame 
 #define K2B_SDIAG_STAMP(i) ((void)0)
 #define K2B_SDIAG_TILE ((void)0)
 #endif
+#ifndef K2B_SXDIAG_STAMP
+#define K2B_SXDIAG_BEGIN ((void)0)
+#define K2B_SXDIAG_STAMP(i) ((void)0)
+#define K2B_SXDIAG_TILE ((void)0)
+#define K2B_SXDIAG_STORES 1
+#endif
 constexpr int CHUNK = 8;                           // frame groups per L2 chunk of the tile walk (as the tile kernel)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -358,6 +364,283 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
     K2B_SDIAG_END;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k2b_lbs_stream_x_kernel: the same design for 49-56 joints and 16 pose k-steps (SMPL-X: 9 x 54 + 20 + 2 = 508 features).
+//
+// What does not carry over from the kernel above is the resident X: 16 k-steps x 16 KiB do not fit, so X walks through a FOUR-slot
+// ring of one k-step each, three k-steps ahead, and the pose phase has one barrier per k-step (the barrier at the top of k-step
+// ks publishes X(ks + 1), which every wave has waited for itself, and frees the slot of k-step ks - 1 for X(ks + 3)).  Pd still
+// goes global -> registers two k-steps ahead, private to the wave.  The transform contraction over 55 joints is
+//   A fragments per entry (1 KiB each):  H0 = hi groups 0-3,  H1 = hi 4-6 | PAD (translation terms),  L0 = lo 0-3,  L1 = lo 4-6 | ZERO
+//   W fragments per 16-vertex tile:      Wh0, Wh1 | ONES, Wl0, Wl1 | 0, Wh1 | tag          (resident in registers for the phase)
+//   T = H0.Wh0 + H1.[Wh1|ONES] + H0.Wl0 + H1.[Wl1|0] + L0.Wh0 + L1.[Wh1|tag]            four LDS reads for six MFMAs
+// LDS: 4 x 16 KiB (X ring) + 2 x 48 KiB (A units) = 160 KiB.
+//
+// Vector-memory operations of a wave in issue order (loads, LDS-DMA fills and stores retire in order; every wait is counted):
+//   pose phase, top of k-step ks:  [wait] [barrier, ks = 1..14]  X(ks + 3) x 2 (ks = 1..12)   W x 5 (ks = 15)   Pd(ks + 2) x 6
+//   transform, top of unit u:      [wait] [barrier]  A(u + 1) x 6   X(next tile, u) x 2 (u < 4)   ... stores x 4 (full tile)
+// Pd(16), Pd(17) are the next tile's k-steps 0 and 1.  Younger than what a wait needs:
+//   k-step 2..13: X(ks + 2), Pd(ks + 1) = 8;  14, 15: one Pd = 6;  0, 1: nothing to wait for (covered by the waits of the units)
+//   unit 0: Pd(17) = 6 (needs W);  units 1..4: X x 2 + stores x 4 = 6 (partial tile: 2);  units 5..7: stores = 4 (partial: 0)
+constexpr int XKS = kStreamXKSteps;
+constexpr int kXRingBytes = 4 * 16 * 1024;
+constexpr int kUnitXBytes = 48 * 1024;             // A operand of one 16-frame unit: 12 entries x 4 fragments
+#ifndef K2B_STREAMX_CHUNK
+#define K2B_STREAMX_CHUNK 8
+#endif
+#define K2B_LDS_READY4(N, b) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory")
+
+namespace {
+struct WalkX {                 // as Walk, with its own chunk length
+    int vgroups, fgroups, item_lo, item_hi, nx;
+    __device__ void init(int vgroups_, int fgroups_, int block, int nblocks) {
+        vgroups = vgroups_; fgroups = fgroups_;
+        const int items = ((fgroups + K2B_STREAMX_CHUNK - 1) / K2B_STREAMX_CHUNK) * vgroups, x = block & 7;
+        item_lo = (int)((long long)items * x / 8); item_hi = (int)((long long)items * (x + 1) / 8);
+        nx = nblocks >> 3;
+    }
+    __device__ void next(int& t, int& fg, int& vg) const {
+        for (;;) {
+            t += nx;
+            const int item = item_lo + t / K2B_STREAMX_CHUNK;
+            if (item >= item_hi) { fg = -1; vg = 0; return; }
+            const int c = item / vgroups;
+            fg = c * K2B_STREAMX_CHUNK + t % K2B_STREAMX_CHUNK; vg = item - c * vgroups;
+            if (fg < fgroups) return;
+        }
+    }
+};
+}  // namespace
+
+__global__ __launch_bounds__(512) void k2b_lbs_stream_x_kernel(const StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [4][16 KiB] X ring | [2][48 KiB] A units
+    unsigned char* const aslots = lds + kXRingBytes;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = lane & 15, g = lane >> 4;
+    const int f32tiles = a.f32_tiles, f16tiles = 2 * f32tiles, nv16 = a.nv16;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    WalkX walk;
+    walk.init(nv16 >> 3, (f32tiles + 3) >> 2, blockIdx.x, a.num_wgs);
+    int wt = (blockIdx.x >> 3) - walk.nx, cfg, cvg;
+    walk.next(wt, cfg, cvg);
+    if (cfg < 0) return;
+    K2B_SXDIAG_BEGIN;
+
+    // X of k-step ks into ring slot ks & 3: wave w moves (k-half w >> 2, frame tile w & 3), hi and lo
+    auto issue_x = [&](int fg, int ks) {
+        const int kh = wave >> 2, ft = wave & 3;
+        int ftc = fg * 4 + ft;
+        ftc = ftc < f32tiles ? ftc : f32tiles - 1;
+        const size_t o = ((size_t)(2 * ks + kh) * f32tiles + ftc) * 512 + lane * 8;
+        unsigned char* dst = lds + (ks & 3) * 16384 + (kh * 8 + ft * 2) * 1024;
+        __builtin_amdgcn_global_load_lds(a.xh + o, dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(a.xl + o, dst + 1024, 16, 0, 0);
+    };
+    // A of one 16-frame unit: 48 contiguous pieces [entry 12][fragment 4]; wave w moves pieces 6 w .. 6 w + 5
+    auto issue_a = [&](int f16, int slot) {
+        f16 = f16 < f16tiles ? f16 : f16tiles - 1;
+        const k2b_half* src = a.a2 + ((size_t)f16 * 48 + 6 * wave) * 512 + lane * 8;
+        unsigned char* dst = aslots + slot * kUnitXBytes + 6 * wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds(src + i * 512, dst + i * 1024, 16, 0, 0);
+    };
+    auto load_pd = [&](half8 (&buf)[3][2], int vg, int ks) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.pd + ((size_t)ks * nv16 + vg * 8 + wave) * 6 * 512) + 3072;
+        gload16<-3072>(buf[0][0], lane16, base); gload16<-2048>(buf[0][1], lane16, base);
+        gload16<-1024>(buf[1][0], lane16, base); gload16<0>(buf[1][1], lane16, base);
+        gload16<1024>(buf[2][0], lane16, base);  gload16<2048>(buf[2][1], lane16, base);
+    };
+
+    const int lx = (g >> 1) * 8192 + (g & 1) * 512 + row * 16;      // lane part of an X fragment address inside a ring slot
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    const unsigned lxa = lds0 + lx;
+    const int la = g * 256 + row * 16;                               // lane part of an A fragment address inside a piece
+    const float inv_scale = 1.0f / kPdScale;
+
+    half8 pb0[3][2], pb1[3][2], pb2[3][2];      // Pd buffers: k-step ks lives in buffer ks % 3 (16 % 3 = 1: the next tile's k-steps 0 and 1
+                                                // land in buffers 1 and 2 and are renamed at the end of the tile)
+    half8 wf[5];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) issue_x(cfg, ks);
+    issue_a(cfg * 8, 0);
+    load_pd(pb0, cvg, 0);
+    load_pd(pb1, cvg, 1);
+    K2B_PD_READY(0, pb0);
+    K2B_PD_READY(0, pb1);
+    wg_barrier();
+
+    while (cfg >= 0) {
+        int nt = wt, nxf, nxv;
+        walk.next(nt, nxf, nxv);
+        const int nfg = nxf >= 0 ? nxf : cfg, nvg = nxf >= 0 ? nxv : cvg;
+        floatx4 vp[8][3];
+
+        // ---- pose phase ------------------------------------------------------------------------------------------------------
+        half8 xq[2][2];
+        auto xread = [&](half8 (&dst)[2], auto ksc, auto fc) {
+            constexpr int ks = decltype(ksc)::value, f = decltype(fc)::value;
+            constexpr int off = (ks & 3) * 16384 + (f >> 1) * 2048 + (f & 1) * 256;
+            lread16<off>(dst[0], lxa); lread16<off + 1024>(dst[1], lxa);
+        };
+        auto kstep = [&](auto ksc, const half8 (&pd)[3][2]) {
+            constexpr int ks = decltype(ksc)::value;
+            auto tile = [&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                half8 (&cur)[2] = xq[f & 1];
+                // (the first fragment of k-step ks + 1 is read at the end of k-step ks: the barrier at the top of ks published it)
+                if constexpr (f < 7) xread(xq[(f + 1) & 1], ksc, std::integral_constant<int, (f + 1) & 7>{});
+                else if constexpr (ks < XKS - 1) xread(xq[0], std::integral_constant<int, ks + 1>{}, std::integral_constant<int, 0>{});
+                if constexpr (f < 7 || ks < XKS - 1) K2B_LDS_READY2(2, cur); else K2B_LDS_READY2(0, cur);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if constexpr (ks == 0) vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[0], pd[c][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[0], pd[c][0], vp[f][c], 0, 0, 0);
+                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[0], pd[c][1], vp[f][c], 0, 0, 0);
+                    vp[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[1], pd[c][0], vp[f][c], 0, 0, 0);
+                }
+            };
+            tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{});
+            tile(std::integral_constant<int, 3>{}); tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
+            tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
+        };
+        // top of k-step ks: wait, barrier, fills and loads as in the table above, then the 72 MFMAs; cur = buffer ks % 3, nxt = (ks + 2) % 3
+        auto step = [&](auto ksc, half8 (&cur)[3][2], half8 (&nxt)[3][2]) {
+            constexpr int ks = decltype(ksc)::value;
+            K2B_SXDIAG_STAMP(ks);
+            if constexpr (ks >= 2 && ks <= 13) K2B_PD_READY(8, cur);
+            else if constexpr (ks >= 14) K2B_PD_READY(6, cur);
+            else K2B_PD_READY(63, cur);                 // (the counter's ceiling: ties the registers to this point, waits for nothing)
+            if constexpr (ks >= 1 && ks <= 14) wg_barrier();
+            if constexpr (ks >= 1 && ks <= 12) issue_x(cfg, ks + 3);
+            if constexpr (ks == XKS - 1) {             // W fragments of this tile's vertices, needed behind the pose phase
+                const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w + ((size_t)cvg * 8 + wave) * 5 * 512) + 2048;   // (13-bit signed offsets)
+                gload16<-2048>(wf[0], lane16, wbase); gload16<-1024>(wf[1], lane16, wbase); gload16<0>(wf[2], lane16, wbase);
+                gload16<1024>(wf[3], lane16, wbase); gload16<2048>(wf[4], lane16, wbase);
+            }
+            if constexpr (ks + 2 < XKS) load_pd(nxt, cvg, ks + 2); else load_pd(nxt, nvg, ks + 2 - XKS);
+            kstep(ksc, cur);
+        };
+        xread(xq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 0>{}, pb0, pb2);   step(std::integral_constant<int, 1>{}, pb1, pb0);
+        step(std::integral_constant<int, 2>{}, pb2, pb1);   step(std::integral_constant<int, 3>{}, pb0, pb2);
+        step(std::integral_constant<int, 4>{}, pb1, pb0);   step(std::integral_constant<int, 5>{}, pb2, pb1);
+        step(std::integral_constant<int, 6>{}, pb0, pb2);   step(std::integral_constant<int, 7>{}, pb1, pb0);
+        step(std::integral_constant<int, 8>{}, pb2, pb1);   step(std::integral_constant<int, 9>{}, pb0, pb2);
+        step(std::integral_constant<int, 10>{}, pb1, pb0);  step(std::integral_constant<int, 11>{}, pb2, pb1);
+        step(std::integral_constant<int, 12>{}, pb0, pb2);  step(std::integral_constant<int, 13>{}, pb1, pb0);
+        step(std::integral_constant<int, 14>{}, pb2, pb1);  step(std::integral_constant<int, 15>{}, pb0, pb2);
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { vp[f][c][i] *= inv_scale; asm volatile("" : "+v"(vp[f][c][i])); }
+
+        // ---- transform phase ---------------------------------------------------------------------------------------------------
+        const int v = (cvg * 8 + wave) * 16 + row;
+        const bool okv = v < a.num_out;
+        int jrow = 0;
+        bool has_joint = false;
+        const size_t row_bytes = (size_t)a.out_stride * 12;
+        unsigned char* const tbase = reinterpret_cast<unsigned char*>(a.out) + (size_t)(cfg * 128) * row_bytes;
+        const unsigned voff = (unsigned)(((size_t)a.out_row0 + v) * 12 + (size_t)(4 * g) * row_bytes);
+        const bool tile_full = cfg * 128 + 127 < a.num_frames && (cvg * 8 + wave) * 16 + 15 < a.num_out;   // wave-uniform
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            K2B_SXDIAG_STAMP(16 + 3 * u);
+            if (u == 0) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4])::"memory");
+            else if (u <= 4) { if (tile_full) wait_vmcnt<6>(); else wait_vmcnt<2>(); }
+            else { if (tile_full) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+            wg_barrier();
+            K2B_SXDIAG_STAMP(17 + 3 * u);
+            if (u == 0 && a.joints_out) {
+                const float tg = (float)wf[4][0];      // lanes g == 3 hold the tag group of their row
+                jrow = (int)__shfl(tg, 48 + row, 64);
+                has_joint = __builtin_amdgcn_ballot_w64(jrow != 0) != 0;
+            }
+            // behind the barrier the other A slot is free, and (from unit 0 on) the whole X ring: next unit's A, next tile's X k-step u
+            if (u < 7) issue_a(cfg * 8 + u + 1, (u + 1) & 1); else issue_a(nfg * 8, 0);
+            if (u < 4) issue_x(nfg, u);
+            floatx4 out[3] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+            half8 af[2][4];
+            floatx4 t[2];
+            const unsigned sa = lds0 + kXRingBytes + (u & 1) * kUnitXBytes + la;
+            lread16<0>(af[0][0], sa); lread16<1024>(af[0][1], sa); lread16<2048>(af[0][2], sa); lread16<3072>(af[0][3], sa);
+            auto entry = [&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n + 1 < 12) {
+                    constexpr int e1 = 4 * ((n + 1) % 3) + (n + 1) / 3;
+                    lread16<e1 * 4096>(af[(n + 1) & 1][0], sa); lread16<e1 * 4096 + 1024>(af[(n + 1) & 1][1], sa);
+                    lread16<e1 * 4096 + 2048>(af[(n + 1) & 1][2], sa); lread16<e1 * 4096 + 3072>(af[(n + 1) & 1][3], sa);
+                }
+                if constexpr (n + 1 < 12) K2B_LDS_READY4(4, af[n & 1]); else if constexpr (n < 12) K2B_LDS_READY4(0, af[n & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (n < 12) {
+                    const half8 (&f)[4] = af[n & 1];
+                    floatx4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[0], wf[0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[1], wf[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[0], wf[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[1], wf[3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[2], wf[0], acc, 0, 0, 0);
+                    t[n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[3], wf[4], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (n > 0) {
+                    constexpr int d = (n - 1) / 3, r = (n - 1) % 3;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (d < 3) out[r][i] = __builtin_fmaf(t[(n - 1) & 1][i], vp[u][d][i], out[r][i]);
+                        else out[r][i] += t[(n - 1) & 1][i];
+                        asm volatile("" : "+v"(out[r][i]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            entry(std::integral_constant<int, 0>{}); entry(std::integral_constant<int, 1>{}); entry(std::integral_constant<int, 2>{});
+            entry(std::integral_constant<int, 3>{}); entry(std::integral_constant<int, 4>{}); entry(std::integral_constant<int, 5>{});
+            entry(std::integral_constant<int, 6>{}); entry(std::integral_constant<int, 7>{}); entry(std::integral_constant<int, 8>{});
+            entry(std::integral_constant<int, 9>{}); entry(std::integral_constant<int, 10>{}); entry(std::integral_constant<int, 11>{});
+            entry(std::integral_constant<int, 12>{});
+            K2B_SXDIAG_STAMP(18 + 3 * u);
+            const int fbase = (cfg * 8 + u) * 16 + 4 * g;
+            if (tile_full) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gstore12(voff, float3r{out[0][i], out[1][i], out[2][i]}, tbase + (size_t)(K2B_SXDIAG_STORES ? u * 16 + i : i) * row_bytes);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = fbase + i;
+                    if (okv && f < a.num_frames) gstore12(voff, float3r{out[0][i], out[1][i], out[2][i]}, tbase + (size_t)(u * 16 + i) * row_bytes);
+                }
+            }
+            if (has_joint) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = fbase + i;
+                    if (jrow != 0 && okv && f < a.num_frames) {
+                        float3v x;
+                        x.x = out[0][i]; x.y = out[1][i]; x.z = out[2][i];
+                        *reinterpret_cast<float3v*>(a.joints_out + ((size_t)f * a.joints_stride + a.joints_row0 + jrow - 1) * 3) = x;
+                    }
+                }
+            }
+        }
+        asm volatile("" : "+v"(pb1[0][0]), "+v"(pb1[0][1]), "+v"(pb1[1][0]), "+v"(pb1[1][1]), "+v"(pb1[2][0]), "+v"(pb1[2][1]),
+                          "+v"(pb2[0][0]), "+v"(pb2[0][1]), "+v"(pb2[1][0]), "+v"(pb2[1][1]), "+v"(pb2[2][0]), "+v"(pb2[2][1]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { pb0[c][h] = pb1[c][h]; pb1[c][h] = pb2[c][h]; }
+        K2B_SXDIAG_STAMP(40);
+        wt = nt; cfg = nxf; cvg = nxv;
+        K2B_SXDIAG_TILE;
+    }
+    wait_vmcnt<0>();
+}
+
 hipError_t launch_skin_stream(const StreamArgs& a_in, int num_cus, hipStream_t stream) {
     if (a_in.num_frames <= 0 || a_in.num_out <= 0) return hipSuccess;
     StreamArgs a = a_in;
@@ -371,6 +654,22 @@ hipError_t launch_skin_stream(const StreamArgs& a_in, int num_cus, hipStream_t s
     const hipError_t e = ensure_dynamic_lds(k2b_lbs_stream_kernel, lds_set, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k2b_lbs_stream_kernel, dim3(wgs), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_skin_stream_x(const StreamArgs& a_in, int num_cus, hipStream_t stream) {
+    if (a_in.num_frames <= 0 || a_in.num_out <= 0) return hipSuccess;
+    StreamArgs a = a_in;
+    if ((a.nv16 & 7) || a.f32_tiles <= 0) return hipErrorInvalidValue;
+    const long long tiles = (long long)(a.nv16 >> 3) * ((a.f32_tiles + 3) >> 2);
+    int wgs = num_cus < 8 ? 8 : num_cus / 8 * 8;
+    if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
+    a.num_wgs = wgs;
+    const size_t lds = (size_t)kXRingBytes + 2 * kUnitXBytes;
+    static std::atomic<unsigned long long> lds_set{0};
+    const hipError_t e = ensure_dynamic_lds(k2b_lbs_stream_x_kernel, lds_set, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k2b_lbs_stream_x_kernel, dim3(wgs), dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -55,6 +55,23 @@ def test_smplx_lbs_matches_oracle_forward():
     assert (j2.cpu() - ref.joints).abs().max() < 5e-6
 
 
+@pytest.mark.parametrize("B", [129, 300])
+def test_smplx_lbs_ragged_multi_tile_batches(B):
+    """Several 128-frame groups with a partial last one: the persistent workgroups of the SMPL-X skinning kernel walk more than
+    one tile (operands of the next tile fetched under the current one) and the last frame group takes the predicated stores."""
+    from keypoints2body_amd import synthetic
+    p = synthetic.make_poses_x(B, seed=11)
+    t = lambda a: torch.tensor(np.asarray(a))
+    with torch.no_grad():
+        ref = H.oracle_model_x()(**{k: t(getattr(p, k)) for k in ("global_orient", "body_pose", "jaw_pose", "leye_pose", "reye_pose",
+                                                                   "left_hand_pose", "right_hand_pose", "betas", "expression", "transl")})
+    pose = np.concatenate([getattr(p, k) for k, _ in POSE_FIELDS], axis=1)
+    shape = np.concatenate([p.betas, p.expression], axis=1)
+    j, v = H.native_model_x().lbs(H.cuda(p.global_orient), H.cuda(pose), H.cuda(shape), H.cuda(p.transl))
+    assert (v.cpu() - ref.vertices).abs().max() < 5e-6
+    assert (j.cpu() - ref.joints).abs().max() < 5e-6
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_smplx_fit_matches_reference_golden(case):
     d = H.load_smplx_case(case)

@@ -82,3 +82,23 @@
         }                                                                                      \
     } while (0)
 #endif
+
+// ---- SMPL-X stream kernel (k2b_lbs_stream_x_kernel) -----------------------------------------------------------------------------
+//   K2B_STREAMX_DIAG 2: s_memtime stamps of the workgroup's SECOND tile, every wave, 41 points (ks = 0..15: top of pose k-step ks,
+//   then per unit u: 16 + 3u before the counted wait, 17 + 3u behind the barrier, 18 + 3u MFMAs issued, before the stores; 40 tile
+//   end): blocks 0 and 77 write [1024 + 2048 b' + wave 64 + i] dwords (tools/dev_lbs_xstamps.py)
+//   K2B_STREAMX_DIAG 5: the stores of a full tile land in the rows of the tile's first 4 frames only (an L2-resident footprint)
+#if K2B_STREAMX_DIAG == 2
+#define K2B_SXDIAG_BEGIN int sd_tile = 0
+#define K2B_SXDIAG_STAMP(i)                                                                    \
+    do { if (sd_tile == 1 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 77))                \
+             reinterpret_cast<unsigned*>(a.dump)[1024 + (blockIdx.x ? 2048 : 0) + wave * 64 + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define K2B_SXDIAG_TILE ++sd_tile
+#define K2B_SXDIAG_STORES 1
+#endif
+#if K2B_STREAMX_DIAG == 5
+#define K2B_SXDIAG_BEGIN ((void)0)
+#define K2B_SXDIAG_STAMP(i) ((void)0)
+#define K2B_SXDIAG_TILE ((void)0)
+#define K2B_SXDIAG_STORES 0
+#endif
