@@ -48,6 +48,10 @@ constexpr int kUnitBytes = 24 * 1024;              // A operand of one 16-frame 
 #define K2B_SDIAG_STAMP(i) ((void)0)
 #define K2B_SDIAG_TILE ((void)0)
 #endif
+#ifndef K2B_SX_SKIP
+#define K2B_SX_SKIP 0          // timing-only builds of the SMPL-X kernel (tools/build_lbs_variants.sh name:"-DK2B_SX_SKIP=n"), a bit mask:
+#endif                         // 1 no stores, 2 no fills behind the prologue, 4 no Pd loads in the loop, 8 no barriers in the loop,
+                               // 16 no LDS reads (results are wrong on purpose; they answer "what does this part cost")
 #ifndef K2B_SXDIAG_STAMP
 #define K2B_SXDIAG_BEGIN ((void)0)
 #define K2B_SXDIAG_STAMP(i) ((void)0)
@@ -70,7 +74,8 @@ __device__ __forceinline__ void gload16(half8& dst, unsigned lane_off, const voi
 // compiler's own waits are lgkmcnt(0) in front of the first use, which stalls a wave on every fragment it has just requested
 template <int OFF>
 __device__ __forceinline__ void lread16(half8& dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+    if constexpr (K2B_SX_SKIP & 16) asm volatile("" : "=v"(dst) : "v"(addr));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 // 12-byte store through a scalar row base and a per-lane 32-bit byte offset (the compiler's own code adds 64-bit vector addresses
 // per store; nobody waits for a store except the end of the kernel)
@@ -513,14 +518,14 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_x_kernel(const StreamArgs 
             if constexpr (ks >= 2 && ks <= 13) K2B_PD_READY(8, cur);
             else if constexpr (ks >= 14) K2B_PD_READY(6, cur);
             else K2B_PD_READY(63, cur);                 // (the counter's ceiling: ties the registers to this point, waits for nothing)
-            if constexpr (ks >= 1 && ks <= 14) wg_barrier();
-            if constexpr (ks >= 1 && ks <= 12) issue_x(cfg, ks + 3);
+            if constexpr (ks >= 1 && ks <= 14) if (!(K2B_SX_SKIP & 8)) wg_barrier();
+            if constexpr (ks >= 1 && ks <= 12 && !(K2B_SX_SKIP & 2)) issue_x(cfg, ks + 3);
             if constexpr (ks == XKS - 1) {             // W fragments of this tile's vertices, needed behind the pose phase
                 const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w + ((size_t)cvg * 8 + wave) * 5 * 512) + 2048;   // (13-bit signed offsets)
                 gload16<-2048>(wf[0], lane16, wbase); gload16<-1024>(wf[1], lane16, wbase); gload16<0>(wf[2], lane16, wbase);
                 gload16<1024>(wf[3], lane16, wbase); gload16<2048>(wf[4], lane16, wbase);
             }
-            if constexpr (ks + 2 < XKS) load_pd(nxt, cvg, ks + 2); else load_pd(nxt, nvg, ks + 2 - XKS);
+            if constexpr (!(K2B_SX_SKIP & 4)) { if constexpr (ks + 2 < XKS) load_pd(nxt, cvg, ks + 2); else load_pd(nxt, nvg, ks + 2 - XKS); }
             kstep(ksc, cur);
         };
         xread(xq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_x_kernel(const StreamArgs 
             if (u == 0) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4])::"memory");
             else if (u <= 4) { if (tile_full) wait_vmcnt<6>(); else wait_vmcnt<2>(); }
             else { if (tile_full) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
-            wg_barrier();
+            if (!(K2B_SX_SKIP & 8)) wg_barrier();
             K2B_SXDIAG_STAMP(17 + 3 * u);
             if (u == 0 && a.joints_out) {
                 const float tg = (float)wf[4][0];      // lanes g == 3 hold the tag group of their row
@@ -562,8 +567,10 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_x_kernel(const StreamArgs 
                 has_joint = __builtin_amdgcn_ballot_w64(jrow != 0) != 0;
             }
             // behind the barrier the other A slot is free, and (from unit 0 on) the whole X ring: next unit's A, next tile's X k-step u
-            if (u < 7) issue_a(cfg * 8 + u + 1, (u + 1) & 1); else issue_a(nfg * 8, 0);
-            if (u < 4) issue_x(nfg, u);
+            if (!(K2B_SX_SKIP & 2)) {
+                if (u < 7) issue_a(cfg * 8 + u + 1, (u + 1) & 1); else issue_a(nfg * 8, 0);
+                if (u < 4) issue_x(nfg, u);
+            }
             floatx4 out[3] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
             half8 af[2][4];
             floatx4 t[2];
@@ -606,7 +613,9 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_x_kernel(const StreamArgs 
             entry(std::integral_constant<int, 12>{});
             K2B_SXDIAG_STAMP(18 + 3 * u);
             const int fbase = (cfg * 8 + u) * 16 + 4 * g;
-            if (tile_full) {
+            if (K2B_SX_SKIP & 1) {
+                asm volatile("" ::"v"(out[0]), "v"(out[1]), "v"(out[2]));
+            } else if (tile_full) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gstore12(voff, float3r{out[0][i], out[1][i], out[2][i]}, tbase + (size_t)(K2B_SXDIAG_STORES ? u * 16 + i : i) * row_bytes);
             } else {
