@@ -188,9 +188,11 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
     // LBS operands: B side of the two GEMMs, f16 hi/lo in fragment order (k2b_lbs.hip)
     {
         const int P = m->P;
-        const int KX = ((P + NB + 2 + 31) / 32) * 2;   // even: the kernel stages 32-deep slices
-        m->k_steps_x = KX;
+        int KX = ((P + NB + 2 + 31) / 32) * 2;         // even: the kernels stage 32-deep slices
         m->groups_a = k2b::tile_groups_a(J);
+        // 49-56 joints with fewer features than SMPL-X (SMPL-H: 477 -> 15 k-steps): one all-zero k-step more buys the stream kernel
+        if (K2B_LBS_STREAM && m->groups_a == 7 && KX < 2 * k2b::kStreamXKSteps) KX = 2 * k2b::kStreamXKSteps;
+        m->k_steps_x = KX;
         m->stream = K2B_LBS_STREAM && m->groups_a == 3 && KX == 2 * k2b::kStreamKSteps;
         m->stream_x = K2B_LBS_STREAM && m->groups_a == 7 && KX == 2 * k2b::kStreamXKSteps;
         HIP_TRY(hipMalloc((void**)&m->dump, 64 * 1024));     // 64 x 3 floats used; the rest is room for diagnostic builds
@@ -274,6 +276,7 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
                 if ((e = upload(&vs.spd, spd.data(), spd.size())) != hipSuccess) return (int)e;
                 if ((e = upload(&vs.sw, sw.data(), sw.size())) != hipSuccess) return (int)e;
             }
+            if (m->stream || m->stream_x) return 0;          // the tile kernel's images stay on the host (SMPL-X: 64 MB less per GPU)
             if ((e = upload(&vs.w2, w2.data(), w2.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdh, pdh.data(), pdh.size())) != hipSuccess) return (int)e;
             if ((e = upload(&vs.pdl, pdl.data(), pdl.size())) != hipSuccess) return (int)e;
