@@ -51,7 +51,8 @@ constexpr int kUnitBytes = 24 * 1024;              // A operand of one 16-frame 
 #ifndef K2B_SX_SKIP
 #define K2B_SX_SKIP 0          // timing-only builds of the SMPL-X kernel (tools/build_lbs_variants.sh name:"-DK2B_SX_SKIP=n"), a bit mask:
 #endif                         // 1 no stores, 2 no fills behind the prologue, 4 no Pd loads in the loop, 8 no barriers in the loop,
-                               // 16 no LDS reads (results are wrong on purpose; they answer "what does this part cost")
+                               // 16 no LDS reads, 32 Pd of vertex group 0 for every tile (always L2-resident)
+                               // (results are wrong on purpose; they answer "what does this part cost")
 #ifndef K2B_SXDIAG_STAMP
 #define K2B_SXDIAG_BEGIN ((void)0)
 #define K2B_SXDIAG_STAMP(i) ((void)0)
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_kernel(const StreamArgs a)
     };
     // Pd of this wave's 16 vertices for k-step ks: 6 consecutive KiB [coordinate 3][hi | lo]
     auto load_pd = [&](half8 (&buf)[3][2], int vg, int ks) {
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.pd + ((size_t)ks * nv16 + vg * 8 + wave) * 6 * 512) + 3072;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.pd + ((size_t)ks * nv16 + ((K2B_SX_SKIP & 32) ? 0 : vg) * 8 + wave) * 6 * 512) + 3072;
         gload16<-3072>(buf[0][0], lane16, base); gload16<-2048>(buf[0][1], lane16, base);
         gload16<-1024>(buf[1][0], lane16, base); gload16<0>(buf[1][1], lane16, base);
         gload16<1024>(buf[2][0], lane16, base);  gload16<2048>(buf[2][1], lane16, base);
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(512) void k2b_lbs_stream_x_kernel(const StreamArgs 
         for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds(src + i * 512, dst + i * 1024, 16, 0, 0);
     };
     auto load_pd = [&](half8 (&buf)[3][2], int vg, int ks) {
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.pd + ((size_t)ks * nv16 + vg * 8 + wave) * 6 * 512) + 3072;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.pd + ((size_t)ks * nv16 + ((K2B_SX_SKIP & 32) ? 0 : vg) * 8 + wave) * 6 * 512) + 3072;
         gload16<-3072>(buf[0][0], lane16, base); gload16<-2048>(buf[0][1], lane16, base);
         gload16<-1024>(buf[1][0], lane16, base); gload16<0>(buf[1][1], lane16, base);
         gload16<1024>(buf[2][0], lane16, base);  gload16<2048>(buf[2][1], lane16, base);
