@@ -46,6 +46,11 @@ HBM_PEAK_GBS = 8000.0
 ROUND = "r04"
 LBS_KERNELS = {"smpl": "k2b_pose_setup_kernel+k2b_lbs_stream_kernel", "smplx": "k2b_pose_setup_kernel+k2b_lbs_tile_kernel"}
 PREWARM_S = 0.3        # seconds of untimed load before the warm-up steps (device clock ramp, see measure())
+# HIP events around the fit launch, the forward and the exchange are recorded on every EVENT_EVERY-th step of the timed region
+# (they are what `roofline.avg_launch_ms` averages: 5 of the default 20 steps of each of the nine blocks).  Four timing events per
+# step cost ~10 us of a 0.57 ms step (same box, back to back: 0.5727 / 0.5746 ms with events on every step, 0.5587 / 0.5653 on
+# every fourth) - instrumentation, not work of the path.  K2B_BENCH_EVENT_EVERY=1 records them on every step.
+EVENT_EVERY = max(1, int(os.environ.get("K2B_BENCH_EVENT_EVERY", "4")))
 
 
 def lbs_bytes_per_frame(model) -> int:
@@ -305,7 +310,11 @@ def main():
         def step(record=False, comm=True):
             """ONE pass of the hot path over this rank's block = ``parallel.fit_forward_exchange``, the very function the public
             ``optimize_params_sequence`` runs for independent frames: fit launch, parameter all-gather enqueued on RCCL's stream,
-            final forward over the OWN block, joints all-gather, wait."""
+            final forward over the OWN block, joints all-gather, wait.  ``record``: HIP events around the fit launch, the forward
+            and the exchange of THIS step (the per-kernel durations of the roofline objects)."""
+            if not record:
+                ex = fit_forward_exchange(lambda: fitter.fit_params(cfg, j3d, init, idx), fitter.final_forward, dist if comm else None, pad_to=per)
+                return ex["local"], ex["joints"], ex["vertices"]
             e0, e1, e2, e3 = ev(), ev(), ev(), ev()
 
             def fit_fn():
@@ -353,8 +362,8 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                out, joints, verts = step(record=True)
+            for i in range(steps):
+                out, joints, verts = step(record=i % EVENT_EVERY == 0)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
@@ -438,6 +447,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "repeats": repeats,                 # timed blocks of `steps` steps; value / ms_per_step are the median block's
+            "event_every": EVENT_EVERY,         # steps between HIP-event samples of the per-kernel durations (roofline.avg_launch_ms)
             "block_ms": r["block_ms"],
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
