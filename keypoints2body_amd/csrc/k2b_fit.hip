@@ -990,9 +990,15 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
             float yQ = 0.f;
             // per-lane rim constants (P_BB row, c_B, P_BA mu_A, mu_B): two 16-byte LDS reads per iteration, for both frames
             const float4 rc0 = *reinterpret_cast<const float4*>(rcl + lane * 8), rc1 = *reinterpret_cast<const float4*>(rcl + lane * 8 + 4);
+            // (both frames unconditionally - a wave's second slot beyond the workgroup's frames reads strips nobody wrote and its
+            //  results are dropped below: without the branch the two frames' chains of LDS round trips interleave, 4096 frames
+            //  0.3610 against 0.3680 ms; hoisting the reads and terms that do not hang on the meeting above it, or dropping the same
+            //  branch from the Adam and publish loops, adds nothing)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (slot0 + h >= F) continue;
+#ifdef K2B_WIDE_PRIORS_BRANCH
+                if (slot0 + h >= F) continue;      // (A/B build: the form before this change)
+#endif
                 const int slot = slot0 + h;
                 const float* xs = slots + slot * SLOT;
                 float yA = 0.f, best = 0.f;
