@@ -1,8 +1,8 @@
 """Development: wall time of ONE optimize_params_frame call (BASELINE configs[0]: a single 22-joint AMASS frame) on the GPU,
 Adam branch (one fused launch) and L-BFGS branch (the reference default: host optimiser over evaluate-only launches)."""
-import sys, time, statistics
+import os, sys, time, statistics
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import keypoints2body_amd as k2b
 from keypoints2body_amd.core.config import FrameOptimizeConfig
 from keypoints2body_amd.models.body_model import BodyModel
