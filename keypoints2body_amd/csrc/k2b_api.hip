@@ -848,7 +848,7 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
                    const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
                    const float* tr_prior, float* go_out,
                    float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream,
-                   int chain_len, int chain_iters) {
+                   int chain_len, int chain_iters, int lb_mode = 0, const k2b::LbfgsArgs* lb_dev = nullptr) {
     k2b_model* model = const_cast<k2b_model*>(model_c);
     if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
     const int pose_dims_all = 3 * (model->J - 1);
@@ -947,6 +947,9 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;
     a.num_cus = device_cus();
+    a.lb_mode = lb_mode; a.lb = lb_dev;
+    if (lb_mode != 0 && (!vsel.empty() || chain_len > 1 || !lb_dev))
+        return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the fused L-BFGS step needs kinematic targets and independent frames");
     if (!vsel.empty())
         return fit_world_vertex_joints(model, cfg, a, a.tr_prior, 0, vsel, vcol, (hipStream_t)stream,
                                        [&](const k2b::FitArgs& e) { return k2b::launch_fit_world(e, (hipStream_t)stream); });
@@ -986,10 +989,24 @@ namespace {
 // One device-driven L-BFGS fit of B frames whose start is ALREADY in the parameter arrays (go, bp, be, tr: in place): state
 // cleared, max_eval + 2 rounds of [closure, step], finalise, loss (+ gradient) at the result.  `ws` = lbfgs_ws_bytes() of
 // stream-ordered scratch, `pres` / `trp` = preserve pose / translation prior centre (device, outside the parameter arrays).
-struct LbfgsWs { unsigned char* base; size_t off_si, off_sv, n_state; float *gbuf, *lbuf; };
+struct LbfgsWs { unsigned char* base; size_t off_si, off_sv, n_state; float *gbuf, *lbuf, *gbuf2, *lbuf2; k2b::LbfgsArgs* la_dev; };
 size_t lbfgs_ws_layout(int B, int P, int H, LbfgsWs* w) {
-    w->n_state = k2b::lbfgs_state_bytes(B, P, H, &w->off_si, &w->off_sv);
-    return w->n_state + ((size_t)B * P + B) * sizeof(float);
+    w->n_state = (k2b::lbfgs_state_bytes(B, P, H, &w->off_si, &w->off_sv) + 15) / 16 * 16;
+    // two closure-result buffers (the fused rounds alternate) and two device copies of the optimiser's arguments
+    const size_t n_res = (2 * ((size_t)B * P + B) * sizeof(float) + 15) / 16 * 16;
+    return w->n_state + n_res + (2 * sizeof(k2b::LbfgsArgs) + 15) / 16 * 16;
+}
+// pointers into the workspace laid out above; returns the first byte behind it (the caller's own scratch)
+float* lbfgs_ws_assign(LbfgsWs* w, unsigned char* ws, int B, int P) {
+    w->base = ws;
+    w->gbuf = reinterpret_cast<float*>(ws + w->n_state);
+    w->lbuf = w->gbuf + (size_t)B * P;
+    w->gbuf2 = w->lbuf + B;
+    w->lbuf2 = w->gbuf2 + (size_t)B * P;
+    const size_t n_res = (2 * ((size_t)B * P + B) * sizeof(float) + 15) / 16 * 16;
+    unsigned char* p = ws + w->n_state + n_res;
+    w->la_dev = reinterpret_cast<k2b::LbfgsArgs*>(p);
+    return reinterpret_cast<float*>(p + (2 * sizeof(k2b::LbfgsArgs) + 15) / 16 * 16);
 }
 int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
               const int32_t* model_joint_index, const float* j3d, const float* conf, const float* pres, const float* trp,
@@ -1014,6 +1031,40 @@ int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_co
     la.loss_in = w.lbuf; la.grad_in = w.gbuf;
     la.sd = reinterpret_cast<double*>(w.base); la.si = reinterpret_cast<int*>(w.base + w.off_si); la.sv = reinterpret_cast<float*>(w.base + w.off_sv);
     const int rounds = max_eval + 2;
+    // One launch per round where the fused kernel takes the frames (24-joint model, the prior over the whole pose, kinematic
+    // targets only, at most four frames per CU): launch r = [step on the result of launch r - 1 | closure]; the last launch =
+    // [finalise | closure] with the caller's outputs.  Two result buffers alternate (a launch reads the one its predecessor
+    // wrote while writing the other).  Otherwise two launches per round.
+    bool fused = w.la_dev != nullptr && model_c->fit_ok && (B + device_cus() - 1) / device_cus() <= 4;
+    if (fused) {
+        const int pose_dims_all = 3 * (model_c->J - 1);
+        const int prior_dims = cfg->prior_pose_dims > 0 ? cfg->prior_pose_dims : (prior->D < pose_dims_all ? prior->D : pose_dims_all);
+        fused = prior->D == pose_dims_all && prior_dims == pose_dims_all && (cfg->num_betas_prior == 0 || cfg->num_betas_prior == model_c->NB);
+        for (int k = 0; k < K && fused; ++k) fused = model_joint_index[k] >= 0 && model_joint_index[k] < model_c->J;
+    }
+    if (fused) {
+        // device copies of the optimiser's arguments: [0] reads buffer A, [1] reads buffer B
+        k2b::LbfgsArgs both[2] = {la, la};
+        both[0].loss_in = w.lbuf;  both[0].grad_in = w.gbuf;
+        both[1].loss_in = w.lbuf2; both[1].grad_in = w.gbuf2;
+        HIP_TRY(hipMemcpyAsync(w.la_dev, both, sizeof both, hipMemcpyHostToDevice, stream));
+        auto fused_launch = [&](int mode, int read_sel, float* loss, float* grad) {
+            return fit_world_impl(model_c, prior, &ec, B, K, model_joint_index, j3d, conf, go, bp, be, tr, pres, trp,
+                                  go, bp, be, tr, loss, grad, stream_v, 1, 0, mode, w.la_dev + read_sel);
+        };
+        // launch 0: closure only, writes A; launch r >= 1 reads (r - 1) & 1 and writes r & 1
+        if (const int rc = closure(w.lbuf, w.gbuf); rc != K2B_OK) return rc;
+        for (int r = 1; r <= rounds; ++r) {
+            const int rd = (r - 1) & 1, wr = r & 1;
+            if (r < rounds) {
+                if (const int rc = fused_launch(1, rd, wr ? w.lbuf2 : w.lbuf, wr ? w.gbuf2 : w.gbuf); rc != K2B_OK) return rc;
+            } else {
+                // the last step consumes result r - 1, then the finalise launch parks every frame and evaluates the result
+                if (const int rc = fused_launch(1, rd, wr ? w.lbuf2 : w.lbuf, wr ? w.gbuf2 : w.gbuf); rc != K2B_OK) return rc;
+                return fused_launch(2, wr, loss_out ? loss_out : (rd ? w.lbuf2 : w.lbuf), grad_out);
+            }
+        }
+    }
     for (int r = 0; r < rounds; ++r) {
         if (const int rc = closure(w.lbuf, w.gbuf); rc != K2B_OK) return rc;
         HIP_TRY(k2b::launch_lbfgs_step(la, stream));
@@ -1063,10 +1114,7 @@ int k2b_fit_world_lbfgs(const k2b_model* model_c, const k2b_prior* prior, const 
     HIP_TRY(hipMallocAsync((void**)&ws, n_opt + ((size_t)B * D + (size_t)B * 3) * sizeof(float), stream));
     auto cleanup = [&](int rc) { (void)hipFreeAsync(ws, stream); return rc; };
 #define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_world_lbfgs: HIP call failed")); } } while (0)
-    w.base = ws;
-    w.gbuf = reinterpret_cast<float*>(ws + w.n_state);
-    w.lbuf = w.gbuf + (size_t)B * P;
-    float *pres = w.lbuf + B, *trp = pres + (size_t)B * D;
+    float *pres = lbfgs_ws_assign(&w, ws, B, P), *trp = pres + (size_t)B * D;
     K2B_TRY_WS(hipMemcpyAsync(pres, preserve ? preserve : bp_in, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
     K2B_TRY_WS(hipMemcpyAsync(trp, tr_prior ? tr_prior : tr_in, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     const struct { const float* src; float* dst; size_t n; } cp[] = {
@@ -1106,10 +1154,7 @@ int k2b_fit_sequence_lbfgs(const k2b_model* model_c, const k2b_prior* prior, con
     HIP_TRY(hipMallocAsync((void**)&ws, n_opt + (size_t)D * sizeof(float), stream));
     auto cleanup = [&](int rc) { (void)hipFreeAsync(ws, stream); return rc; };
 #define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_sequence_lbfgs: HIP call failed")); } } while (0)
-    w.base = ws;
-    w.gbuf = reinterpret_cast<float*>(ws + w.n_state);
-    w.lbuf = w.gbuf + P;
-    float* pres = w.lbuf + 1;
+    float* pres = lbfgs_ws_assign(&w, ws, 1, P);
     k2b_fit_config fc = *cfg;
     for (int t = 0; t < T; ++t) {
         float *go = go_out + (size_t)t * 3, *bp = bp_out + (size_t)t * D, *be = be_out + (size_t)t * NB, *tr = tr_out + (size_t)t * 3;

@@ -49,6 +49,7 @@
 
 #include "k2b_internal.h"
 #include "k2b_lanes.h"
+#include "k2b_lbfgs_device.h"
 
 // Per-phase s_memtime stamps of the split shape's two roles live outside this file: tools/build_fit_stamps.sh compiles it with
 // -DK2B_FIT_DIAG_HEADER=<tools/fit_diag.h>, which fills the hooks below (iteration 50 of one workgroup, device printf behind the loop).
@@ -182,11 +183,11 @@ __device__ __forceinline__ float butterfly16_half_sum(const float (&v)[16], int 
 // (Measured and NOT kept in round 4: `split` with eight row waves of one component each (12 waves: the row waves' component
 //  chain is halved but runs in the tree wave's shadow either way - 0.2465 against 0.2428 ms at 1024 frames), and a 16-wave shape
 //  with one frame per wave (twice the tree instructions per frame: 0.399 against 0.294 ms at 2048 frames).)
-enum { MODE_SPLIT = 0, MODE_SPLIT_PAIRED = 1, MODE_PAIRED = 2, MODE_WIDE = 3 };
+enum { MODE_SPLIT = 0, MODE_SPLIT_PAIRED = 1, MODE_PAIRED = 2, MODE_WIDE = 3, MODE_SPLIT_LBFGS = 4 };   // 4: split + the L-BFGS step as a prologue
 
 template <int MODE> struct Shape {
     static constexpr bool SPLIT = MODE != MODE_PAIRED;
-    static constexpr bool PAIR = MODE != MODE_SPLIT;
+    static constexpr bool PAIR = MODE != MODE_SPLIT && MODE != MODE_SPLIT_LBFGS;
     static constexpr int NROW = MODE == MODE_WIDE ? 8 : 4;                                   // row waves (split shapes)
     static constexpr int NWAVES = SPLIT ? 2 * NROW : MAXW;                                   // as many tree waves as row waves
     static constexpr int CPW = MG / NROW;                                                    // mixture components per row wave
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
     //            both roles for its two slots.
     // (split shape with one or two frames: the tree wave of slot s is wave 4 + ((s + 2) & 3), i.e. it sits on the SIMD of an idle
     //  row slot instead of sharing its own row wave's SIMD - the two roles of a frame are co-critical and issue-bound together)
-    const bool spread = MODE == MODE_SPLIT && F <= 2 && wave >= 4;
+    constexpr bool SPLIT1 = MODE == MODE_SPLIT || MODE == MODE_SPLIT_LBFGS;     // one frame per row / tree wave
+    const bool spread = SPLIT1 && F <= 2 && wave >= 4;
     const int slot0 = (PAIR ? 2 : 1) * (SPLIT ? (spread ? ((wave + 2) & 3) : (wave < NROW ? wave : wave - NROW)) : wave);
     const bool do_row = slot0 < F && (!SPLIT || wave < NROW);     // rim of the prior, priors in row layout, Adam, results
     const bool do_tree = slot0 < F && (!SPLIT || wave >= NROW);   // kinematics, joint loss, analytic backward
@@ -385,6 +387,32 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         wconf = (a.joint_w * a.joint_w) * (c * c);
     }
 
+    // ---- L-BFGS step as a prologue (MODE_SPLIT_LBFGS; FitArgs::lb_mode): the frame's row wave consumes the previous launch's
+    // closure result and writes the point this launch evaluates into the parameter arrays it is about to read.  One launch per
+    // round instead of two (a closure launch is ~8 us, a step launch ~5-7 us, and the host paces the 80 launches of a fit).
+    // Staging LDS for the history pairs: everything between the y exchange and the rim products (y, J_dirs table, lo fragments,
+    // rim products: 116 KiB that nothing has written yet - a barrier separates the step from their first use), shared out over the
+    // workgroup's frames (one frame: 116 KiB, four: 29 KiB = 28 pairs of a 128-float parameter vector).
+    if constexpr (MODE == MODE_SPLIT_LBFGS) {
+        if (a.lb_mode != 0) {
+            if (do_row && f_valid[0]) {
+                LbfgsArgs la = *a.lb;
+                la.finalize = a.lb_mode == 2 ? 1 : 0;
+                constexpr int kFree = (MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX + PLO_FLOATS + WX_FLOATS) * 4;
+                const int per_wave = (kFree / F) & ~15;
+                const int PL = (la.P + 63) / 64 * 64;
+                const int head = 2 * la.H * (int)sizeof(double);
+                int pairs = (per_wave - head) / (2 * PL * (int)sizeof(float));
+                pairs = pairs < 0 ? 0 : pairs;
+                unsigned char* stage = reinterpret_cast<unsigned char*>(yx) + wave * per_wave;
+                lbfgs_dev::lbfgs_step_frame(la, f[0], lane, stage, pairs);
+            }
+            // the parameters written above are read back below by other lanes of the same wave (and by nobody else in this launch)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __syncthreads();
+        }
+    }
+
     // ---- 2. parameters and optimiser state (row layout) -----------------------------------
     auto param_ptr = [&](int fr, int p, const float* go, const float* bp, const float* be, const float* tr) -> const float* {
         if (p < 3) return go + (size_t)fr * 3 + p;
@@ -500,7 +528,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         const half8 bl1 = *reinterpret_cast<const half8*>(cth_lo + 32 + 8 * cg);
         const half8* rf = rimfrag + comp * kPriorRimFragEntries + ridx;
         const half8 rh0 = rf[0], rl0 = rf[21], rh1 = rf[42], rl1 = rf[63];   // rim rows 64..68 as a fifth row tile (rows 69..79 are zero)
-        if constexpr (MODE == MODE_SPLIT) {
+        if constexpr (SPLIT1) {
             // Step-major over the five row tiles: five independent accumulation chains advance together, so a dependent MFMA never
             // waits for its predecessor's result.  The split shapes' row waves carry two components and their chain - not the tree's -
             // is the iteration's critical path at <= 4 frames per CU (stamps: DESIGN.md 4.1): -2.7 % at 1024 frames; in the two-frames-
@@ -1268,8 +1296,11 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     // k2b_fit_config::debug_launch_shape forces a shape regardless of the batch size, so that the parity tests can
     // drive every shape with the small golden cases (1..3: the 8-wave shapes of rounds 1-3; 4: the 16-wave one)
     static const int forced[5] = {0, MODE_SPLIT, MODE_SPLIT_PAIRED, MODE_PAIRED, MODE_WIDE};
-    auto cap_of = [](int m) { return m == MODE_SPLIT ? 4 : ((m == MODE_PAIRED || m == MODE_WIDE) ? MAXS : MAXW); };
-    if (a.force_shape) {
+    auto cap_of = [](int m) { return (m == MODE_SPLIT || m == MODE_SPLIT_LBFGS) ? 4 : ((m == MODE_PAIRED || m == MODE_WIDE) ? MAXS : MAXW); };
+    if (a.lb_mode != 0) {
+        if (fpw > 4) return hipErrorInvalidValue;     // the caller checks (k2b_api.hip: lbfgs_run)
+        mode = MODE_SPLIT_LBFGS;
+    } else if (a.force_shape) {
         mode = forced[a.force_shape];
         // small (test) batches fill the shape's slots; batches of a CU count or more keep one workgroup per CU where the shape can
         if (a.num_frames < a.num_cus) { fpw = cap_of(mode); if (fpw > a.num_frames) fpw = a.num_frames; }
@@ -1284,6 +1315,7 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
         case MODE_SPLIT: K2B_LAUNCH_NB(MODE_SPLIT); break;
         case MODE_SPLIT_PAIRED: K2B_LAUNCH_NB(MODE_SPLIT_PAIRED); break;
         case MODE_PAIRED: K2B_LAUNCH_NB(MODE_PAIRED); break;
+        case MODE_SPLIT_LBFGS: K2B_LAUNCH_NB(MODE_SPLIT_LBFGS); break;
         default: K2B_LAUNCH_NB(MODE_WIDE); break;
     }
 #undef K2B_LAUNCH_NB

@@ -62,6 +62,11 @@ struct FitArgs {
     int num_cus;
     int chain_len, chain_iters; // warm-start chain: num_frames SEQUENCES of chain_len frames each (1: independent frames)
     int force_shape;            // 0 = chosen by the batch size; 1..4 = split / split-paired / paired / wide (k2b_fit_config::debug_launch_shape)
+    // L-BFGS step as a prologue of the closure's own launch (k2b_lbfgs.hip): 0 = none; 1 = every frame's row wave first consumes the
+    // PREVIOUS launch's loss / gradient (lb->loss_in / grad_in) and writes the next point into the parameter arrays, then the launch
+    // evaluates it; 2 = the finalise step (accepted points into the parameter arrays), then the evaluation.  Split shape only.
+    int lb_mode;
+    const struct LbfgsArgs* lb; // device copy of the optimiser's arguments
 };
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);
