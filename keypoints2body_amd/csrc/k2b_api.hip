@@ -848,7 +848,8 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
                    const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
                    const float* tr_prior, float* go_out,
                    float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream,
-                   int chain_len, int chain_iters, int lb_mode = 0, const k2b::LbfgsArgs* lb_dev = nullptr) {
+                   int chain_len, int chain_iters, int lb_mode = 0, const k2b::LbfgsArgs* lb_dev = nullptr,
+                   const k2b::LbfgsArgs* lb_host = nullptr) {
     k2b_model* model = const_cast<k2b_model*>(model_c);
     if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
     const int pose_dims_all = 3 * (model->J - 1);
@@ -948,6 +949,7 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     a.chain_iters = chain_iters;
     a.num_cus = device_cus();
     a.lb_mode = lb_mode; a.lb = lb_dev;
+    if (lb_host) { a.lb_loss = lb_host->loss_in; a.lb_grad = lb_host->grad_in; a.lb_history = lb_host->H; }
     if (lb_mode != 0 && (!vsel.empty() || chain_len > 1 || !lb_dev))
         return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the fused L-BFGS step needs kinematic targets and independent frames");
     if (!vsel.empty())
@@ -1052,6 +1054,14 @@ int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_co
             return fit_world_impl(model_c, prior, &ec, B, K, model_joint_index, j3d, conf, go, bp, be, tr, pres, trp,
                                   go, bp, be, tr, loss, grad, stream_v, 1, 0, mode, w.la_dev + read_sel);
         };
+        if ((B + device_cus() - 1) / device_cus() <= 2) {
+            // at most two frames per CU: the whole fit is ONE persistent launch - rounds closures, each followed by its step on an
+            // idle wave of the workgroup, the finalise pass and the closure at the result (k2b_fit.hip, lb_mode 3)
+            k2b_fit_config pc = ec;
+            pc.num_iters = rounds + 1;
+            return fit_world_impl(model_c, prior, &pc, B, K, model_joint_index, j3d, conf, go, bp, be, tr, pres, trp,
+                                  go, bp, be, tr, loss_out ? loss_out : w.lbuf2, grad_out, stream_v, 1, 0, 3, w.la_dev, &both[0]);
+        }
         // launch 0: closure only, writes A; launch r >= 1 reads (r - 1) & 1 and writes r & 1
         if (const int rc = closure(w.lbuf, w.gbuf); rc != K2B_OK) return rc;
         for (int r = 1; r <= rounds; ++r) {

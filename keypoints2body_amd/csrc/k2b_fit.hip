@@ -394,7 +394,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
     // rim products: 116 KiB that nothing has written yet - a barrier separates the step from their first use), shared out over the
     // workgroup's frames (one frame: 116 KiB, four: 29 KiB = 28 pairs of a 128-float parameter vector).
     if constexpr (MODE == MODE_SPLIT_LBFGS) {
-        if (a.lb_mode != 0) {
+        if (a.lb_mode == 1 || a.lb_mode == 2) {
             if (do_row && f_valid[0]) {
                 LbfgsArgs la = *a.lb;
                 la.finalize = a.lb_mode == 2 ? 1 : 0;
@@ -410,6 +410,26 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
             // the parameters written above are read back below by other lanes of the same wave (and by nobody else in this launch)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __syncthreads();
+        }
+    }
+
+    // persistent L-BFGS (lb_mode 3): see the tree waves' loop
+    const bool lb_loop = MODE == MODE_SPLIT_LBFGS && a.lb_mode == 3;
+    bool lb_step = false;
+    int lb_frame = 0, lb_pairs = 0;
+    unsigned char* lb_stage = nullptr;
+    if constexpr (MODE == MODE_SPLIT_LBFGS) {
+        if (lb_loop && wave >= NROW && wave - NROW < F) {
+            const int sl = wave - NROW;                           // slot whose optimiser this (idle) tree wave is
+            lb_frame = blockIdx.x * F + sl;
+            lb_step = lb_frame < a.num_frames;
+            // staging LDS: the half of the lo-fragment area the split shape never writes (components 0..3 keep theirs in registers)
+            constexpr int kFree = PLO_FLOATS * 4 / 2;
+            const int per = (kFree / F) & ~15;
+            const int P_ = 3 + D + NB + 3, PL = (P_ + 63) / 64 * 64, head = 2 * a.lb_history * (int)sizeof(double);
+            lb_pairs = (per - head) / (2 * PL * (int)sizeof(float));
+            lb_pairs = lb_pairs < 0 ? 0 : lb_pairs;
+            lb_stage = reinterpret_cast<unsigned char*>(plo) + sl * per;
         }
     }
 
@@ -874,10 +894,36 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                 K2B_FSTAMP(0);
                 __syncthreads();
                 K2B_FSTAMP(1);
-                if (do_tree) tree_pass(it == nit - 1);
+                if (do_tree) tree_pass(it == nit - 1 || lb_loop);
                 K2B_FSTAMP(2);
                 __syncthreads();
                 K2B_FSTAMP(3);
+                if constexpr (MODE == MODE_SPLIT_LBFGS) {
+                    // persistent L-BFGS (lb_mode 3, at most two frames per workgroup): the IDLE tree wave 4 + s is slot s's optimiser.
+                    // Between two more barriers it consumes the closure result the row wave has just written (loss, gradient: global,
+                    // same CU) and puts the next point into the parameter arrays, which the row wave then reads back: a round is one
+                    // iteration of this loop (~2.5 us) + one step, no launch.  Behind the last step: the finalise pass (accepted points).
+                    if (lb_loop) {
+                        __syncthreads();
+                        if (lb_step && it < nit - 1) {
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            // the optimiser's scalars (and the closure's loss) are wave-uniform loads = SCALAR loads, and the scalar cache
+                            // is not coherent with the vector stores that wrote them a round ago: drop it (a fresh launch starts clean)
+                            __builtin_amdgcn_s_dcache_inv();
+                            LbfgsArgs la = *a.lb;
+                            la.finalize = 0;
+                            lbfgs_dev::lbfgs_step_frame(la, lb_frame, lane, lb_stage, lb_pairs);
+                            if (it == nit - 2) {
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                __builtin_amdgcn_s_dcache_inv();
+                                la.finalize = 1;
+                                lbfgs_dev::lbfgs_step_frame(la, lb_frame, lane, lb_stage, lb_pairs);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        }
+                        __syncthreads();
+                    }
+                }
             }
             K2B_FSTAMP_TREE_PRINT;
         }
@@ -1180,12 +1226,31 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                 while (__hip_atomic_load(row_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
             K2B_FSTAMP(5);
-            if (do_row) row_prior(last);
+            if (do_row) row_prior(last || lb_loop);
             K2B_FSTAMP(6);
             __syncthreads();
             K2B_FSTAMP(7);
-            if (do_row) row_finish(it, last);
+            if (do_row) row_finish(it, last || lb_loop);
             K2B_FSTAMP(8);
+            if constexpr (MODE == MODE_SPLIT_LBFGS) {
+                if (lb_loop) {       // closure result out, next point in (the optimiser runs on the slot's idle tree wave in between)
+                    const int P_ = 3 + D + NB + 3;
+                    if (do_row && f_valid[0] && !last) {
+                        float* gdst = const_cast<float*>(a.lb_grad) + (size_t)f[0] * P_;
+                        gdst[pA] = g0[0];
+                        if (actB) gdst[pB] = g1[0];
+                        if (lane == 0) const_cast<float*>(a.lb_loss)[f[0]] = loss_total[0];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    __syncthreads();
+                    __syncthreads();
+                    if (do_row && !last) {
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        x0[0] = *param_ptr(f[0], pA, a.go_in, a.bp_in, a.be_in, a.tr_in);
+                        x1[0] = actB ? *param_ptr(f[0], pB, a.go_in, a.bp_in, a.be_in, a.tr_in) : 0.f;
+                    }
+                }
+            }
         }
         K2B_FSTAMP_ROW_PRINT;
             if (!PAIR && chain && do_row && f_valid[0]) {     // this step's frame: row s chain_len + step
@@ -1298,7 +1363,7 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
     static const int forced[5] = {0, MODE_SPLIT, MODE_SPLIT_PAIRED, MODE_PAIRED, MODE_WIDE};
     auto cap_of = [](int m) { return (m == MODE_SPLIT || m == MODE_SPLIT_LBFGS) ? 4 : ((m == MODE_PAIRED || m == MODE_WIDE) ? MAXS : MAXW); };
     if (a.lb_mode != 0) {
-        if (fpw > 4) return hipErrorInvalidValue;     // the caller checks (k2b_api.hip: lbfgs_run)
+        if (fpw > (a.lb_mode == 3 ? 2 : 4)) return hipErrorInvalidValue;     // the caller checks (k2b_api.hip: lbfgs_run)
         mode = MODE_SPLIT_LBFGS;
     } else if (a.force_shape) {
         mode = forced[a.force_shape];

@@ -67,6 +67,10 @@ struct FitArgs {
     // evaluates it; 2 = the finalise step (accepted points into the parameter arrays), then the evaluation.  Split shape only.
     int lb_mode;
     const struct LbfgsArgs* lb; // device copy of the optimiser's arguments
+    // 3 = persistent: the whole fit in ONE launch (num_iters = rounds + 1 closures; at most two frames per workgroup); the row wave
+    // writes each closure's result to lb_loss / lb_grad (= lb->loss_in / grad_in), lb_history = lb->H (host copies: no device read)
+    const float *lb_loss, *lb_grad;
+    int lb_history;
 };
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);
