@@ -1244,7 +1244,8 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     __syncthreads();
                     __syncthreads();
-                    if (do_row && !last) {
+                    if (do_row) {    // (also behind the last closure: whatever the zero-step Adam update made of a non-finite gradient, the
+                                     //  result is the parked point in the parameter arrays)
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                         x0[0] = *param_ptr(f[0], pA, a.go_in, a.bp_in, a.be_in, a.tr_in);
                         x1[0] = actB ? *param_ptr(f[0], pB, a.go_in, a.bp_in, a.be_in, a.tr_in) : 0.f;
