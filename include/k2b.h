@@ -208,8 +208,10 @@ int k2b_fit_sequence(const k2b_model *model, const k2b_prior *prior, const k2b_f
  * never move); the optimiser itself - two-loop recursion over up to `history_size` pairs (<= 0: torch's 100), strong-Wolfe
  * bracket / zoom with torch's cubic interpolation, tolerance_grad / tolerance_change / max_iter / max_eval = max_iter * 5 / 4
  * exits - is a state machine on the device, one independent instance per frame (k2b_lbfgs.hip).  The call only queues
- * launches on `stream` (max_eval + 2 rounds of [closure, optimiser step] + the final evaluation): no host synchronisation,
- * nothing is read back.  Arguments as k2b_fit_world; preserve_pose / transl_prior_target NULL = the initial body pose /
+ * launches on `stream`: no host synchronisation, nothing is read back.  max_eval + 2 rounds of [closure, optimiser step] + the
+ * final evaluation, as ONE launch for at most two frames per CU (the rounds are iterations of the fused kernel's loop, the
+ * optimiser runs on an idle wave of the workgroup), one launch per round up to four frames per CU (the step as a prologue
+ * of the closure's launch), two launches per round beyond that and for the larger models; the result does not depend on which.  Arguments as k2b_fit_world; preserve_pose / transl_prior_target NULL = the initial body pose /
  * translation; *_out may alias *_in; loss_out dev [B] and grad_out dev [B][3 + 3(J-1) + NB + 3] (either may be NULL) receive
  * loss and gradient AT the result.  Frames never interact (torch couples the frames of a batch in one line search; the
  * reference only ever passes one frame).  At most 192 parameters per frame.
