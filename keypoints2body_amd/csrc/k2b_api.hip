@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -1037,7 +1038,9 @@ int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_co
     // targets only, at most four frames per CU): launch r = [step on the result of launch r - 1 | closure]; the last launch =
     // [finalise | closure] with the caller's outputs.  Two result buffers alternate (a launch reads the one its predecessor
     // wrote while writing the other).  Otherwise two launches per round.
-    bool fused = w.la_dev != nullptr && model_c->fit_ok && (B + device_cus() - 1) / device_cus() <= 4;
+    // (development: K2B_LBFGS_SCHEME = 1 forces two launches per round, 2 the fused rounds wherever they apply; tools/dev_lbfgs_schemes.py)
+    static const int scheme_env = [] { const char* e = getenv("K2B_LBFGS_SCHEME"); return e ? atoi(e) : 0; }();
+    bool fused = scheme_env != 1 && w.la_dev != nullptr && model_c->fit_ok && (B + device_cus() - 1) / device_cus() <= 4;
     if (fused) {
         const int pose_dims_all = 3 * (model_c->J - 1);
         const int prior_dims = cfg->prior_pose_dims > 0 ? cfg->prior_pose_dims : (prior->D < pose_dims_all ? prior->D : pose_dims_all);
@@ -1054,7 +1057,7 @@ int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_co
             return fit_world_impl(model_c, prior, &ec, B, K, model_joint_index, j3d, conf, go, bp, be, tr, pres, trp,
                                   go, bp, be, tr, loss, grad, stream_v, 1, 0, mode, w.la_dev + read_sel);
         };
-        if ((B + device_cus() - 1) / device_cus() <= 2) {
+        if (scheme_env != 2 && (B + device_cus() - 1) / device_cus() <= 2) {
             // at most two frames per CU: the whole fit is ONE persistent launch - rounds closures, each followed by its step on an
             // idle wave of the workgroup, the finalise pass and the closure at the result (k2b_fit.hip, lb_mode 3)
             k2b_fit_config pc = ec;

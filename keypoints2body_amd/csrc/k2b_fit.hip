@@ -880,6 +880,31 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         //  the row waves issue few instructions and are starved either way, the tree waves are what the SIMD must keep fed)
         __builtin_amdgcn_s_setprio(3);
         const int steps = PAIR ? 1 : a.chain_len;
+        // persistent L-BFGS (lb_mode 3, at most two frames per workgroup): the IDLE tree wave 4 + s is slot s's optimiser, its state -
+        // 27 scalars, eight vectors, the history in LDS by ring slot - RESIDENT in registers and LDS for the whole fit (the state
+        // arrays in global memory are only written at the end).  Between two more barriers per iteration it consumes the closure
+        // result the row wave has just written (loss, gradient: global memory, same CU) and puts the next point into the parameter
+        // arrays, which the row wave then reads back: a round is one iteration of this loop (~2.5 us) + ~1 us of optimiser, no
+        // launch.  Behind the last step every frame parks at its accepted point.  (The tree pass keeps its ONE call site below: a
+        // second inlined copy is contracted differently by the compiler and the closures stop being bit-identical.)
+        LbfgsArgs la{};
+        if constexpr (MODE == MODE_SPLIT_LBFGS) {
+            if (lb_loop) la = *a.lb;
+        }
+        la.finalize = 0;
+        lbfgs_dev::Frame fr(la);                                        // (unbound: touches no memory; bound below where an optimiser runs)
+        if constexpr (MODE == MODE_SPLIT_LBFGS) {
+            if (lb_loop) {
+                double* lds_al = reinterpret_cast<double*>(lb_stage);
+                float* lds_hist = reinterpret_cast<float*>(lb_stage + (size_t)2 * la.H * sizeof(double));
+                fr.bind(lb_step ? lb_frame : 0, lane, lds_hist, lds_al, lb_pairs);
+                fr.resident = true;
+#pragma unroll
+                for (int w = 0; w < lbfgs_dev::SV_HIST; ++w)
+#pragma unroll
+                    for (int k = 0; k < lbfgs_dev::EPL; ++k) fr.V[w][k] = 0.f;
+            }
+        }
         for (int step = 0; step < steps; ++step) {
             const int nit = step == 0 ? a.num_iters : a.chain_iters;
             if (!PAIR && step > 0 && tk >= 0) {           // targets of this step's frame (sequence s, frame row s chain_len + step)
@@ -899,26 +924,20 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                 __syncthreads();
                 K2B_FSTAMP(3);
                 if constexpr (MODE == MODE_SPLIT_LBFGS) {
-                    // persistent L-BFGS (lb_mode 3, at most two frames per workgroup): the IDLE tree wave 4 + s is slot s's optimiser.
-                    // Between two more barriers it consumes the closure result the row wave has just written (loss, gradient: global,
-                    // same CU) and puts the next point into the parameter arrays, which the row wave then reads back: a round is one
-                    // iteration of this loop (~2.5 us) + one step, no launch.  Behind the last step: the finalise pass (accepted points).
                     if (lb_loop) {
                         __syncthreads();
                         if (lb_step && it < nit - 1) {
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                            // the optimiser's scalars (and the closure's loss) are wave-uniform loads = SCALAR loads, and the scalar cache
-                            // is not coherent with the vector stores that wrote them a round ago: drop it (a fresh launch starts clean)
+                            // (the closure's loss is a wave-uniform = SCALAR load, and the scalar cache is not coherent with the row wave's
+                            //  vector store of a round ago: drop it)
                             __builtin_amdgcn_s_dcache_inv();
-                            LbfgsArgs la = *a.lb;
-                            la.finalize = 0;
-                            lbfgs_dev::lbfgs_step_frame(la, lb_frame, lane, lb_stage, lb_pairs);
-                            if (it == nit - 2) {
-                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                                __builtin_amdgcn_s_dcache_inv();
-                                la.finalize = 1;
-                                lbfgs_dev::lbfgs_step_frame(la, lb_frame, lane, lb_stage, lb_pairs);
+                            if (fr.s.phase != lbfgs_dev::PH_DONE) {
+                                const float* gsrc = la.grad_in + (size_t)lb_frame * la.P;
+#pragma unroll
+                                for (int k = 0; k < lbfgs_dev::EPL; ++k) fr.GN[k] = fr.has(k) ? gsrc[lane + 64 * k] : 0.f;
+                                lbfgs_dev::lbfgs_consume(fr, (double)la.loss_in[lb_frame]);
                             }
+                            if (it == nit - 2) { if (fr.s.phase != lbfgs_dev::PH_INIT) fr.park(); fr.save(); }
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                         }
                         __syncthreads();

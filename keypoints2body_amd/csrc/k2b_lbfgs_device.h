@@ -4,6 +4,11 @@
 #pragma once
 #include "k2b_internal.h"
 
+// No FMA contraction in the optimiser: its code is inlined into three kernels (the step kernel, the closure's prologue, the
+// persistent loop), and what the compiler fuses depends on the context - a one-ulp difference in a search direction is enough for
+// the line searches to part ways.  Separate multiplies and adds are also what the float32 tensors of torch (and the numpy twin) do.
+#pragma clang fp contract(off)
+
 namespace k2b {
 namespace lbfgs_dev {
 
@@ -80,7 +85,7 @@ typedef float Vec[EPL];
 // staged in LDS by one burst of loads.
 struct Frame {
     const LbfgsArgs& a;
-    const int f, lane, P, H;
+    int f, lane, P, H;
     double* sd;
     int* si;
     float* sv;
@@ -90,10 +95,21 @@ struct Frame {
     float* lds_hist;                             // [pair][y | s][PL]: staged history (dynamic LDS), PL = 64 * ceil(P / 64)
     double* lds_al;                              // [H] alphas of the two-loop recursion, then [H] rho of the pairs (oldest first)
     int lds_pairs, PL;
-    __device__ __forceinline__ Frame(const LbfgsArgs& a_, int f_, int lane_, float* lds_hist_, double* lds_al_, int lds_pairs_)
-        : a(a_), f(f_), lane(lane_), P(a_.P), H(a_.H), sd(a_.sd + (size_t)f_ * (SD_RO + a_.H)), si(a_.si + (size_t)f_ * SI_COUNT),
-          sv(a_.sv + (size_t)f_ * (size_t)(SV_HIST + 2 * a_.H) * a_.P), lds_hist(lds_hist_), lds_al(lds_al_), lds_pairs(lds_pairs_),
-          PL((a_.P + 63) / 64 * 64) {
+    bool resident;                               // the object lives across rounds (persistent launch): LDS keeps the pairs BY RING SLOT, nothing is re-staged
+    // (unbound: touches no memory - a kernel may declare the object and bind it only where an optimiser really runs)
+    __device__ __forceinline__ explicit Frame(const LbfgsArgs& a_)
+        : a(a_), f(0), lane(0), P(0), H(0), sd(nullptr), si(nullptr), sv(nullptr), lds_hist(nullptr), lds_al(nullptr), lds_pairs(0), PL(0),
+          resident(false) {}
+    __device__ __forceinline__ Frame(const LbfgsArgs& a_, int f_, int lane_, float* lds_hist_, double* lds_al_, int lds_pairs_) : Frame(a_) {
+        bind(f_, lane_, lds_hist_, lds_al_, lds_pairs_);
+    }
+    // frame f_ of the batch: pointers, then the 27 scalars of its state
+    __device__ __forceinline__ void bind(int f_, int lane_, float* lds_hist_, double* lds_al_, int lds_pairs_) {
+        f = f_; lane = lane_; P = a.P; H = a.H;
+        sd = a.sd + (size_t)f_ * (SD_RO + a.H); si = a.si + (size_t)f_ * SI_COUNT;
+        sv = a.sv + (size_t)f_ * (size_t)(SV_HIST + 2 * a.H) * a.P;
+        lds_hist = lds_hist_; lds_al = lds_al_; lds_pairs = lds_pairs_;
+        PL = (a.P + 63) / 64 * 64;
         s.loss = sd[SD_LOSS]; s.prev_loss = sd[SD_PREV_LOSS]; s.hdiag = sd[SD_HDIAG]; s.t = sd[SD_T]; s.t_prev = sd[SD_T_PREV];
         s.f_prev = sd[SD_F_PREV]; s.gtd_prev = sd[SD_GTD_PREV]; s.f0 = sd[SD_F0]; s.gtd0 = sd[SD_GTD0]; s.dnorm = sd[SD_DNORM];
         s.bt0 = sd[SD_BT0]; s.bt1 = sd[SD_BT1]; s.bf0 = sd[SD_BF0]; s.bf1 = sd[SD_BF1]; s.bg0 = sd[SD_BG0]; s.bg1 = sd[SD_BG1];
@@ -207,32 +223,50 @@ struct Frame {
                 new_slot = slot; ro_new = 1.0 / ys;
                 if (lane == 0) sd[SD_RO + slot] = ro_new;
             }
-            // the pairs of the recursion, oldest first: one burst of loads into LDS (the new pair from registers), rho beside them
-            const int nold = s.nold, staged = nold < lds_pairs ? nold : lds_pairs;
+            // the pairs of the recursion.  One step per launch: oldest first, one burst of loads into LDS (the new pair from registers),
+            // rho beside them.  Resident object: LDS holds every pair since it was made, indexed by its ring slot - only the new pair
+            // (and its rho) is written.
+            const int nold = s.nold, staged = resident ? lds_pairs : (nold < lds_pairs ? nold : lds_pairs);
             double* const lds_ro = lds_al + H;
-            for (int i = lane; i < nold; i += 64) {
-                int sl = s.head + i; sl = sl >= H ? sl - H : sl;
-                lds_ro[i] = sl == new_slot ? ro_new : sd[SD_RO + sl];
-            }
-#pragma unroll 4
-            for (int i = 0; i < staged; ++i) {
-                int sl = s.head + i; sl = sl >= H ? sl - H : sl;
-                const float *Y = hist_y(sl), *S = hist_s(sl);
-                float* dst = lds_hist + (size_t)i * 2 * PL;
+            if (resident) {
+                if (new_slot >= 0) {
+                    if (lane == 0) lds_ro[new_slot] = ro_new;
+                    if (new_slot < lds_pairs) {
+                        float* dst = lds_hist + (size_t)new_slot * 2 * PL;
 #pragma unroll
-                for (int k = 0; k < EPL; ++k) {
-                    if (lane + 64 * k < PL) {
-                        const bool in = has(k);
-                        dst[lane + 64 * k] = sl == new_slot ? ty[k] : (in ? Y[lane + 64 * k] : 0.f);
-                        dst[PL + lane + 64 * k] = sl == new_slot ? ts[k] : (in ? S[lane + 64 * k] : 0.f);
+                        for (int k = 0; k < EPL; ++k)
+                            if (lane + 64 * k < PL) { dst[lane + 64 * k] = ty[k]; dst[PL + lane + 64 * k] = ts[k]; }
+                    }
+                }
+            } else {
+                for (int i = lane; i < nold; i += 64) {
+                    int sl = s.head + i; sl = sl >= H ? sl - H : sl;
+                    lds_ro[i] = sl == new_slot ? ro_new : sd[SD_RO + sl];
+                }
+#pragma unroll 4
+                for (int i = 0; i < staged; ++i) {
+                    int sl = s.head + i; sl = sl >= H ? sl - H : sl;
+                    const float *Y = hist_y(sl), *S = hist_s(sl);
+                    float* dst = lds_hist + (size_t)i * 2 * PL;
+#pragma unroll
+                    for (int k = 0; k < EPL; ++k) {
+                        if (lane + 64 * k < PL) {
+                            const bool in = has(k);
+                            dst[lane + 64 * k] = sl == new_slot ? ty[k] : (in ? Y[lane + 64 * k] : 0.f);
+                            dst[PL + lane + 64 * k] = sl == new_slot ? ts[k] : (in ? S[lane + 64 * k] : 0.f);
+                        }
                     }
                 }
             }
+            // (LDS index of pair i / ring slot sl: its position in the staged burst, or the slot itself)
+            auto lidx = [&](int i, int sl) { return resident ? sl : i; };
             auto pair_y = [&](int i, int sl, int k) -> float {
-                return i < staged ? lds_hist[(size_t)i * 2 * PL + lane + 64 * k] : (has(k) ? hist_y(sl)[lane + 64 * k] : 0.f);
+                const int li = lidx(i, sl);
+                return li < staged ? lds_hist[(size_t)li * 2 * PL + lane + 64 * k] : (has(k) ? hist_y(sl)[lane + 64 * k] : 0.f);
             };
             auto pair_s = [&](int i, int sl, int k) -> float {
-                return i < staged ? lds_hist[(size_t)i * 2 * PL + PL + lane + 64 * k] : (has(k) ? hist_s(sl)[lane + 64 * k] : 0.f);
+                const int li = lidx(i, sl);
+                return li < staged ? lds_hist[(size_t)li * 2 * PL + PL + lane + 64 * k] : (has(k) ? hist_s(sl)[lane + 64 * k] : 0.f);
             };
             // two-loop recursion: q = -g; backward over the pairs, r = q Hdiag; forward
             Vec q;
@@ -243,7 +277,7 @@ struct Frame {
                 double p = 0.0;
 #pragma unroll
                 for (int k = 0; k < EPL; ++k) if (lane + 64 * k < PL) p += (double)pair_s(i, sl, k) * (double)q[k];
-                const double ali = wave_sum_d(p) * lds_ro[i];
+                const double ali = wave_sum_d(p) * lds_ro[lidx(i, sl)];
                 if (lane == 0) lds_al[i] = ali;
                 const float af = (float)ali;
 #pragma unroll
@@ -257,7 +291,7 @@ struct Frame {
                 double p = 0.0;
 #pragma unroll
                 for (int k = 0; k < EPL; ++k) if (lane + 64 * k < PL) p += (double)pair_y(i, sl, k) * (double)q[k];
-                const double be = wave_sum_d(p) * lds_ro[i];
+                const double be = wave_sum_d(p) * lds_ro[lidx(i, sl)];
                 const float cf = (float)(lds_al[i] - be);
 #pragma unroll
                 for (int k = 0; k < EPL; ++k) if (lane + 64 * k < PL) q[k] = q[k] + cf * pair_s(i, sl, k);
@@ -419,14 +453,10 @@ struct Frame {
 // One call = one closure result consumed per frame.  `finalize`: no result is consumed; every frame's ACCEPTED point goes into the
 // parameter arrays (frames still in a line search when the rounds run out fall back to it), for the final loss evaluation.
 // lds = 2 H doubles (alphas, rho) followed by lds_pairs staged history pairs of 2 x 64 ceil(P / 64) floats, private to the wave.
-__device__ __forceinline__ void lbfgs_step_frame(const LbfgsArgs& a, int f, int lane, unsigned char* lds, int lds_pairs) {
-    double* lds_al = reinterpret_cast<double*>(lds);
-    float* lds_hist = reinterpret_cast<float*>(lds + (size_t)2 * a.H * sizeof(double));
-    Frame fr(a, f, lane, lds_hist, lds_al, lds_pairs);
-    fr.load_vectors(a.grad_in + (size_t)f * a.P);
-    if (a.finalize) { if (fr.s.phase != PH_INIT) fr.park(); return; }
-    if (fr.s.phase == PH_DONE) return;
-    const double f_new = (double)a.loss_in[f];
+// one closure result (loss f_new, gradient in fr.GN) through the state machine
+__device__ __forceinline__ void lbfgs_consume(Frame& fr, double f_new) {
+    const LbfgsArgs& a = fr.a;
+    const int lane = fr.lane;
     if (fr.s.phase == PH_INIT) {
         // x = the start (already in the parameter arrays), first closure result
         float gm = 0.f;
@@ -442,9 +472,19 @@ __device__ __forceinline__ void lbfgs_step_frame(const LbfgsArgs& a, int f, int 
         else fr.start_iteration();
     } else if (fr.s.phase == PH_BRACKET) {
         fr.bracket(f_new);
-    } else {
+    } else if (fr.s.phase == PH_ZOOM) {
         fr.zoom_receive(f_new);
     }
+}
+
+__device__ __forceinline__ void lbfgs_step_frame(const LbfgsArgs& a, int f, int lane, unsigned char* lds, int lds_pairs) {
+    double* lds_al = reinterpret_cast<double*>(lds);
+    float* lds_hist = reinterpret_cast<float*>(lds + (size_t)2 * a.H * sizeof(double));
+    Frame fr(a, f, lane, lds_hist, lds_al, lds_pairs);
+    fr.load_vectors(a.grad_in + (size_t)f * a.P);
+    if (a.finalize) { if (fr.s.phase != PH_INIT) fr.park(); return; }
+    if (fr.s.phase == PH_DONE) return;
+    lbfgs_consume(fr, (double)a.loss_in[f]);
     fr.save();
 }
 
@@ -455,3 +495,5 @@ __host__ __device__ inline size_t lbfgs_lds_bytes(int H, int P, int pairs) {
 
 }  // namespace lbfgs_dev
 }  // namespace k2b
+
+#pragma clang fp contract(fast)      // (the translation units are built with -ffp-contract=fast)

@@ -86,17 +86,18 @@ def test_device_lbfgs_frames_are_independent_of_their_batch():
 def test_device_lbfgs_launch_schemes_agree_bitwise():
     """Three ways the rounds reach the device, chosen by the batch size: the whole fit in one persistent launch (at most two frames per
     CU), the step as a prologue of the closure's launch (at most four), and two launches per round (beyond).  The same frames must
-    come out bit-identical whichever scheme their batch takes."""
-    props = torch.cuda.get_device_properties(0)
-    cus = props.multi_processor_count
+    come out bit-identical whichever scheme their batch takes (the optimiser's code is inlined into three kernels: it is compiled
+    without FMA contraction, and the tree pass keeps a single call site per kernel - either one left to the compiler cost a ulp in a
+    few gradients of hundreds, and thirty L-BFGS iterations later the frames had parted ways)."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
     j3d, init = _problem(5 * cus, seed=13)
     cfg = native.default_fit_config()
     run = lambda n: native.fit_world_lbfgs(H.native_model(), H.native_prior(), cfg, list(range(22)), j3d[:n].contiguous(), None,
-                                           *[t[:n].contiguous() for t in init], max_iter=12, lr=1e-2)
-    small, mid, big = run(24), run(3 * cus), run(5 * cus)        # persistent | fused rounds | two launches per round
+                                           *[t[:n].contiguous() for t in init], max_iter=30, lr=1e-2)
+    small, mid, big = run(2 * cus), run(3 * cus), run(5 * cus)        # persistent | fused rounds | two launches per round
     for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
-        assert torch.equal(small[k], mid[k][:24]), k
-        assert torch.equal(small[k], big[k][:24]), k
+        assert torch.equal(small[k], mid[k][:2 * cus]), k
+        assert torch.equal(small[k], big[k][:2 * cus]), k
         assert torch.equal(mid[k], big[k][:3 * cus]), k
 
 
