@@ -849,8 +849,7 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
                    const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
                    const float* tr_prior, float* go_out,
                    float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream,
-                   int chain_len, int chain_iters, int lb_mode = 0, const k2b::LbfgsArgs* lb_dev = nullptr,
-                   const k2b::LbfgsArgs* lb_host = nullptr) {
+                   int chain_len, int chain_iters, int lb_mode = 0, const k2b::LbfgsArgs* lb_host = nullptr) {
     k2b_model* model = const_cast<k2b_model*>(model_c);
     if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
     const int pose_dims_all = 3 * (model->J - 1);
@@ -949,9 +948,9 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     a.chain_len = chain_len > 1 ? chain_len : 1;
     a.chain_iters = chain_iters;
     a.num_cus = device_cus();
-    a.lb_mode = lb_mode; a.lb = lb_dev;
-    if (lb_host) { a.lb_loss = lb_host->loss_in; a.lb_grad = lb_host->grad_in; a.lb_history = lb_host->H; }
-    if (lb_mode != 0 && (!vsel.empty() || chain_len > 1 || !lb_dev))
+    a.lb_mode = lb_mode;
+    if (lb_host) { a.lbv = *lb_host; a.lb_loss = lb_host->loss_in; a.lb_grad = lb_host->grad_in; a.lb_history = lb_host->H; }
+    if (lb_mode != 0 && (!vsel.empty() || chain_len > 1 || !lb_host))
         return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the fused L-BFGS step needs kinematic targets and independent frames");
     if (!vsel.empty())
         return fit_world_vertex_joints(model, cfg, a, a.tr_prior, 0, vsel, vcol, (hipStream_t)stream,
@@ -992,12 +991,12 @@ namespace {
 // One device-driven L-BFGS fit of B frames whose start is ALREADY in the parameter arrays (go, bp, be, tr: in place): state
 // cleared, max_eval + 2 rounds of [closure, step], finalise, loss (+ gradient) at the result.  `ws` = lbfgs_ws_bytes() of
 // stream-ordered scratch, `pres` / `trp` = preserve pose / translation prior centre (device, outside the parameter arrays).
-struct LbfgsWs { unsigned char* base; size_t off_si, off_sv, n_state; float *gbuf, *lbuf, *gbuf2, *lbuf2; k2b::LbfgsArgs* la_dev; };
+struct LbfgsWs { unsigned char* base; size_t off_si, off_sv, n_state; float *gbuf, *lbuf, *gbuf2, *lbuf2; bool state_cleared; };   // (state_cleared: the caller did)
 size_t lbfgs_ws_layout(int B, int P, int H, LbfgsWs* w) {
     w->n_state = (k2b::lbfgs_state_bytes(B, P, H, &w->off_si, &w->off_sv) + 15) / 16 * 16;
-    // two closure-result buffers (the fused rounds alternate) and two device copies of the optimiser's arguments
+    // two closure-result buffers (the fused rounds alternate)
     const size_t n_res = (2 * ((size_t)B * P + B) * sizeof(float) + 15) / 16 * 16;
-    return w->n_state + n_res + (2 * sizeof(k2b::LbfgsArgs) + 15) / 16 * 16;
+    return w->n_state + n_res;
 }
 // pointers into the workspace laid out above; returns the first byte behind it (the caller's own scratch)
 float* lbfgs_ws_assign(LbfgsWs* w, unsigned char* ws, int B, int P) {
@@ -1007,18 +1006,17 @@ float* lbfgs_ws_assign(LbfgsWs* w, unsigned char* ws, int B, int P) {
     w->gbuf2 = w->lbuf + B;
     w->lbuf2 = w->gbuf2 + (size_t)B * P;
     const size_t n_res = (2 * ((size_t)B * P + B) * sizeof(float) + 15) / 16 * 16;
-    unsigned char* p = ws + w->n_state + n_res;
-    w->la_dev = reinterpret_cast<k2b::LbfgsArgs*>(p);
-    return reinterpret_cast<float*>(p + (2 * sizeof(k2b::LbfgsArgs) + 15) / 16 * 16);
+    return reinterpret_cast<float*>(ws + w->n_state + n_res);
 }
 int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_config* cfg, int32_t B, int32_t K,
               const int32_t* model_joint_index, const float* j3d, const float* conf, const float* pres, const float* trp,
               float* go, float* bp, float* be, float* tr, float* loss_out, float* grad_out, int max_iter, int H, double lr,
-              double tol_g, double tol_c, const LbfgsWs& w, void* stream_v) {
+              double tol_g, double tol_c, LbfgsWs& w, void* stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
     const int NB = model_c->NB, D = 3 * (model_c->J - 1), P = 3 + D + NB + 3;
     const int max_eval = max_iter * 5 / 4;                               // torch's default
-    HIP_TRY(hipMemsetAsync(w.base, 0, w.off_sv, stream));               // scalars and integers: phase INIT (vectors are written before they are read)
+    if (!w.state_cleared) HIP_TRY(hipMemsetAsync(w.base, 0, w.off_sv, stream));   // scalars and integers: phase INIT (vectors are written before they are read)
+    w.state_cleared = false;
     k2b_fit_config ec = *cfg;
     ec.num_iters = 1;
     ec.step_size = 0.0;                                                  // evaluate-only: the closure
@@ -1040,7 +1038,7 @@ int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_co
     // wrote while writing the other).  Otherwise two launches per round.
     // (development: K2B_LBFGS_SCHEME = 1 forces two launches per round, 2 the fused rounds wherever they apply; tools/dev_lbfgs_schemes.py)
     static const int scheme_env = [] { const char* e = getenv("K2B_LBFGS_SCHEME"); return e ? atoi(e) : 0; }();
-    bool fused = scheme_env != 1 && w.la_dev != nullptr && model_c->fit_ok && (B + device_cus() - 1) / device_cus() <= 4;
+    bool fused = scheme_env != 1 && model_c->fit_ok && (B + device_cus() - 1) / device_cus() <= 4;
     if (fused) {
         const int pose_dims_all = 3 * (model_c->J - 1);
         const int prior_dims = cfg->prior_pose_dims > 0 ? cfg->prior_pose_dims : (prior->D < pose_dims_all ? prior->D : pose_dims_all);
@@ -1048,14 +1046,13 @@ int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_co
         for (int k = 0; k < K && fused; ++k) fused = model_joint_index[k] >= 0 && model_joint_index[k] < model_c->J;
     }
     if (fused) {
-        // device copies of the optimiser's arguments: [0] reads buffer A, [1] reads buffer B
+        // the optimiser's arguments travel in the launch's own arguments: [0] reads result buffer A, [1] reads B
         k2b::LbfgsArgs both[2] = {la, la};
         both[0].loss_in = w.lbuf;  both[0].grad_in = w.gbuf;
         both[1].loss_in = w.lbuf2; both[1].grad_in = w.gbuf2;
-        HIP_TRY(hipMemcpyAsync(w.la_dev, both, sizeof both, hipMemcpyHostToDevice, stream));
         auto fused_launch = [&](int mode, int read_sel, float* loss, float* grad) {
             return fit_world_impl(model_c, prior, &ec, B, K, model_joint_index, j3d, conf, go, bp, be, tr, pres, trp,
-                                  go, bp, be, tr, loss, grad, stream_v, 1, 0, mode, w.la_dev + read_sel);
+                                  go, bp, be, tr, loss, grad, stream_v, 1, 0, mode, &both[read_sel]);
         };
         if (scheme_env != 2 && (B + device_cus() - 1) / device_cus() <= 2) {
             // at most two frames per CU: the whole fit is ONE persistent launch - rounds closures, each followed by its step on an
@@ -1063,7 +1060,7 @@ int lbfgs_run(const k2b_model* model_c, const k2b_prior* prior, const k2b_fit_co
             k2b_fit_config pc = ec;
             pc.num_iters = rounds + 1;
             return fit_world_impl(model_c, prior, &pc, B, K, model_joint_index, j3d, conf, go, bp, be, tr, pres, trp,
-                                  go, bp, be, tr, loss_out ? loss_out : w.lbuf2, grad_out, stream_v, 1, 0, 3, w.la_dev, &both[0]);
+                                  go, bp, be, tr, loss_out ? loss_out : w.lbuf2, grad_out, stream_v, 1, 0, 3, &both[0]);
         }
         // launch 0: closure only, writes A; launch r >= 1 reads (r - 1) & 1 and writes r & 1
         if (const int rc = closure(w.lbuf, w.gbuf); rc != K2B_OK) return rc;
@@ -1173,11 +1170,9 @@ int k2b_fit_sequence_lbfgs(const k2b_model* model_c, const k2b_prior* prior, con
         float *go = go_out + (size_t)t * 3, *bp = bp_out + (size_t)t * D, *be = be_out + (size_t)t * NB, *tr = tr_out + (size_t)t * 3;
         const float *sgo = t ? go - 3 : go_in, *sbp = t ? bp - D : bp_in, *sbe = t ? be - NB : be_in, *str = t ? tr - 3 : tr_in;
         // start of this frame = the start given (frame 0) or the previous frame's result; its body pose is also what is preserved
-        K2B_TRY_WS(hipMemcpyAsync(go, sgo, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        K2B_TRY_WS(hipMemcpyAsync(bp, sbp, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        K2B_TRY_WS(hipMemcpyAsync(be, sbe, (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        K2B_TRY_WS(hipMemcpyAsync(tr, str, 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        K2B_TRY_WS(hipMemcpyAsync(pres, sbp, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        // (one small launch: the four parameter rows, the preserve pose and the cleared optimiser state)
+        K2B_TRY_WS(k2b::launch_lbfgs_frame_prep(go, sgo, bp, sbp, be, sbe, tr, str, pres, D, NB, w.base, w.off_sv, stream));
+        w.state_cleared = true;
         fc.pose_preserve_weight = t ? cfg->pose_preserve_weight : 0.0f;
         const int iters = t ? followup_iters : first_iters;
         const int H = history_size < iters ? history_size : iters;

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
     if constexpr (MODE == MODE_SPLIT_LBFGS) {
         if (a.lb_mode == 1 || a.lb_mode == 2) {
             if (do_row && f_valid[0]) {
-                LbfgsArgs la = *a.lb;
+                LbfgsArgs la = a.lbv;
                 la.finalize = a.lb_mode == 2 ? 1 : 0;
                 constexpr int kFree = (MAXS * YX_STRIDE + 64 * DD_STRIDE_MAX + PLO_FLOATS + WX_FLOATS) * 4;
                 const int per_wave = (kFree / F) & ~15;
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         // second inlined copy is contracted differently by the compiler and the closures stop being bit-identical.)
         LbfgsArgs la{};
         if constexpr (MODE == MODE_SPLIT_LBFGS) {
-            if (lb_loop) la = *a.lb;
+            if (lb_loop) la = a.lbv;
         }
         la.finalize = 0;
         lbfgs_dev::Frame fr(la);                                        // (unbound: touches no memory; bound below where an optimiser runs)

@@ -26,6 +26,19 @@ constexpr int kPriorImageFloats = 2 * 5 * 64 * 4 + kPriorMaxGauss * 2 * 64 + kPr
 constexpr int kPriorFrag32Halfs = kPriorMaxGauss * 4 * 4 * 64 * 8;
 
 // Kernel arguments of the fused fit (passed by value).
+// Arguments of the device L-BFGS (k2b_lbfgs.hip); defined here because the fused fit kernel carries a copy (FitArgs::lbv).
+struct LbfgsArgs {
+    int B, P, D, NB, H;                  // frames, parameters per frame (3 + D + NB + 3), pose / shape widths, history slots
+    int max_iter, max_eval;
+    double lr, tol_g, tol_c;             // lr, tolerance_grad, tolerance_change
+    float *go, *bp, *be, *tr;            // the point to evaluate next, in the closure's own parameter arrays (in / out)
+    const float *loss_in, *grad_in;      // closure result at that point: [B], [B][P]
+    double* sd;                          // state: scalars, integers, vectors (lbfgs_state_bytes)
+    int* si;
+    float* sv;
+    int finalize;                        // 1: no result consumed, every frame's accepted point -> parameter arrays
+};
+
 struct FitArgs {
     // model (device)
     // tree tables are indexed by LANE: lanes follow the DFS pre-order of the kinematic tree
@@ -66,7 +79,7 @@ struct FitArgs {
     // PREVIOUS launch's loss / gradient (lb->loss_in / grad_in) and writes the next point into the parameter arrays, then the launch
     // evaluates it; 2 = the finalise step (accepted points into the parameter arrays), then the evaluation.  Split shape only.
     int lb_mode;
-    const struct LbfgsArgs* lb; // device copy of the optimiser's arguments
+    LbfgsArgs lbv;              // the optimiser's arguments (by value: no device copy to keep in step)
     // 3 = persistent: the whole fit in ONE launch (num_iters = rounds + 1 closures; at most two frames per workgroup); the row wave
     // writes each closure's result to lb_loss / lb_grad (= lb->loss_in / grad_in), lb_history = lb->H (host copies: no device read)
     const float *lb_loss, *lb_grad;
@@ -255,19 +268,10 @@ inline hipError_t ensure_dynamic_lds(Kernel kernel, std::atomic<unsigned long lo
 
 // ---- device-resident L-BFGS (k2b_lbfgs.hip): one state machine per frame, one closure result consumed per step launch ----------
 constexpr int kLbfgsMaxHistory = 100;    // torch.optim.LBFGS's default history_size
-struct LbfgsArgs {
-    int B, P, D, NB, H;                  // frames, parameters per frame (3 + D + NB + 3), pose / shape widths, history slots
-    int max_iter, max_eval;
-    double lr, tol_g, tol_c;             // lr, tolerance_grad, tolerance_change
-    float *go, *bp, *be, *tr;            // the point to evaluate next, in the closure's own parameter arrays (in / out)
-    const float *loss_in, *grad_in;      // closure result at that point: [B], [B][P]
-    double* sd;                          // state: scalars, integers, vectors (lbfgs_state_bytes)
-    int* si;
-    float* sv;
-    int finalize;                        // 1: no result consumed, every frame's accepted point -> parameter arrays
-};
 size_t lbfgs_state_bytes(int B, int P, int H, size_t* off_si, size_t* off_sv);
 hipError_t launch_lbfgs_step(const LbfgsArgs& a, hipStream_t stream);
+hipError_t launch_lbfgs_frame_prep(float* go, const float* sgo, float* bp, const float* sbp, float* be, const float* sbe, float* tr,
+                                   const float* str, float* pres, int D, int NB, void* state, size_t state_bytes, hipStream_t stream);
 
 // Geodesic angle (degrees) between n pairs of axis-angle rotations (evaluation metric, k2b_metrics.hip).
 hipError_t launch_angular_error(const float* pred, const float* gt, float* out, long long n, hipStream_t stream);

@@ -30,6 +30,25 @@ __global__ __launch_bounds__(64) void k2b_lbfgs_step_kernel(const LbfgsArgs a, i
     lbfgs_step_frame(a, blockIdx.x, threadIdx.x, lbfgs_lds, lds_pairs);
 }
 
+// start of one frame of a warm-start sequence: parameters and preserve pose from their sources (the previous frame's result),
+// the optimiser's scalars and integers cleared (phase INIT) - one launch instead of five copies and a memset
+__global__ __launch_bounds__(256) void k2b_lbfgs_frame_prep_kernel(float* go, const float* sgo, float* bp, const float* sbp, float* be,
+                                                                   const float* sbe, float* tr, const float* str, float* pres, int D, int NB,
+                                                                   unsigned int* state, int state_words) {
+    const int i = threadIdx.x;
+    for (int e = i; e < D; e += 256) { const float v = sbp[e]; bp[e] = v; pres[e] = v; }
+    for (int e = i; e < NB; e += 256) be[e] = sbe[e];
+    if (i < 3) { go[i] = sgo[i]; tr[i] = str[i]; }
+    for (int e = i; e < state_words; e += 256) state[e] = 0u;
+}
+
+hipError_t launch_lbfgs_frame_prep(float* go, const float* sgo, float* bp, const float* sbp, float* be, const float* sbe, float* tr,
+                                   const float* str, float* pres, int D, int NB, void* state, size_t state_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(k2b_lbfgs_frame_prep_kernel, dim3(1), dim3(256), 0, stream, go, sgo, bp, sbp, be, sbe, tr, str, pres, D, NB,
+                       reinterpret_cast<unsigned int*>(state), (int)(state_bytes / 4));
+    return hipGetLastError();
+}
+
 size_t lbfgs_state_bytes(int B, int P, int H, size_t* off_si, size_t* off_sv) {
     size_t n = (size_t)B * (SD_RO + H) * sizeof(double);
     *off_si = n;
