@@ -935,7 +935,9 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                                 const float* gsrc = la.grad_in + (size_t)lb_frame * la.P;
 #pragma unroll
                                 for (int k = 0; k < lbfgs_dev::EPL; ++k) fr.GN[k] = fr.has(k) ? gsrc[lane + 64 * k] : 0.f;
-                                lbfgs_dev::lbfgs_consume(fr, (double)la.loss_in[lb_frame]);
+                                const float* lp = la.loss_in + lb_frame;
+                                asm volatile("" : "+v"(lp));      // (a per-lane address: a VECTOR load, through the L1 the row wave's store went through)
+                                lbfgs_dev::lbfgs_consume(fr, (double)*lp);
                             }
                             if (it == nit - 2) { if (fr.s.phase != lbfgs_dev::PH_INIT) fr.park(); fr.save(); }
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
