@@ -101,6 +101,32 @@ def test_device_lbfgs_launch_schemes_agree_bitwise():
         assert torch.equal(mid[k], big[k][:3 * cus]), k
 
 
+def test_device_lbfgs_sixteen_beta_model_takes_the_same_schemes():
+    """The 16-beta instantiations of the fused kernel (91 parameters per frame) through the persistent launch and through two
+    launches per round: bit-identical, and the betas move."""
+    from keypoints2body_amd import synthetic
+    from keypoints2body_amd.native import NativeModel
+    c = synthetic.make_body_model(seed=3, num_vertices=512, num_betas=16)
+    model = NativeModel(c.v_template, c.shapedirs, c.posedirs, c.J_regressor, c.lbs_weights, c.parents, c.extra_vertex_ids)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 5 * cus
+    p = synthetic.make_poses(B, seed=21)
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+    go, bp, tr = t(p.global_orient), t(p.body_pose), t(p.transl)
+    be = torch.linspace(-1.0, 1.0, 16).repeat(B, 1).cuda() * 0.5
+    j, _ = model.lbs(go, bp, be, tr, want_vertices=False)
+    j3d = j[:, :22].contiguous()
+    init = (go * 0.8, bp * 0.8, torch.zeros_like(be), tr + 0.02)
+    cfg = native.default_fit_config()
+    run = lambda n: native.fit_world_lbfgs(model, H.native_prior(), cfg, list(range(22)), j3d[:n].contiguous(), None,
+                                           *[x[:n].contiguous() for x in init], max_iter=10, lr=1e-2)
+    small, big = run(8), run(B)
+    for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+        assert torch.equal(small[k], big[k][:8]), k
+        assert torch.isfinite(big[k]).all()
+    assert small["betas"].abs().max() > 1e-3
+
+
 def test_device_lbfgs_minimises_and_respects_the_optimiser_membership():
     B = 64
     j3d, init = _problem(B, seed=9)
