@@ -99,6 +99,15 @@ def test_device_lbfgs_launch_schemes_agree_bitwise():
         assert torch.equal(small[k], mid[k][:2 * cus]), k
         assert torch.equal(small[k], big[k][:2 * cus]), k
         assert torch.equal(mid[k], big[k][:3 * cus]), k
+    # more history pairs than the staging LDS of any scheme holds (60 iterations; 30 / 28 / 47 pairs fit): the pairs beyond it are
+    # read from global memory, in the resident optimiser too
+    long = lambda n: native.fit_world_lbfgs(H.native_model(), H.native_prior(), cfg, list(range(22)), j3d[:n].contiguous(), None,
+                                            *[t[:n].contiguous() for t in init], max_iter=60, lr=1e-2, tolerance_grad=0.0,
+                                            tolerance_change=0.0)
+    a, b, c = long(2 * cus), long(3 * cus), long(5 * cus)
+    for k in ("global_orient", "body_pose", "betas", "transl", "loss"):
+        assert torch.equal(a[k], b[k][:2 * cus]), k
+        assert torch.equal(a[k], c[k][:2 * cus]), k
 
 
 def test_device_lbfgs_sixteen_beta_model_takes_the_same_schemes():
