@@ -219,6 +219,8 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
     const int F = a.frames_per_wg;           // frame slots of this workgroup (split <= 4, split-paired <= 8, paired <= 16)
     int* row_sync = &row_sync_cell;
     if (tid == 0) *row_sync = 0;                 // visible to every wave after the first barrier of the loop
+    __shared__ int lb_done_cell[2];               // persistent L-BFGS: slot s's optimiser has finished (written between barriers 3 and 4)
+    if (tid < 2) lb_done_cell[tid] = 1;
 
     // ---- 0. rim of the precisions, mu and c of the core rows -> LDS (shared by the workgroup) ----------
     {
@@ -939,10 +941,17 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                                 asm volatile("" : "+v"(lp));      // (a per-lane address: a VECTOR load, through the L1 the row wave's store went through)
                                 lbfgs_dev::lbfgs_consume(fr, (double)*lp);
                             }
-                            if (it == nit - 2) { if (fr.s.phase != lbfgs_dev::PH_INIT) fr.park(); fr.save(); }
+                            // rounds ran out inside a line search: back to the accepted point (a finished frame parked itself)
+                            if (it == nit - 2 && fr.s.phase != lbfgs_dev::PH_INIT && fr.s.phase != lbfgs_dev::PH_DONE) fr.park();
+                            if (lane == 0) lb_done_cell[wave - NROW] = fr.s.phase == lbfgs_dev::PH_DONE ? 1 : 0;
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                         }
                         __syncthreads();
+                        // every optimiser of the workgroup is done: the closures left would evaluate the same points again - skip to
+                        // the final one (the flags are read by every wave behind the same barrier: uniform)
+                        const bool all_done = lb_done_cell[0] != 0 && lb_done_cell[1] != 0;
+                        if (lb_step && (it == nit - 2 || (all_done && it < nit - 2))) fr.save();
+                        if (all_done && it < nit - 2) it = nit - 2;
                     }
                 }
             }
@@ -1265,6 +1274,7 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     __syncthreads();
                     __syncthreads();
+                    if (lb_done_cell[0] != 0 && lb_done_cell[1] != 0 && it < nit - 2) it = nit - 2;   // (as the tree waves: every optimiser is done)
                     if (do_row) {    // (also behind the last closure: whatever the zero-step Adam update made of a non-finite gradient, the
                                      //  result is the parked point in the parameter arrays)
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
