@@ -235,7 +235,8 @@ int k2b_fit_world_lbfgs(const k2b_model *model, const k2b_prior *prior, const k2
  * the given start (*_in: one row) with first_iters iterations and no preserve term (world_space.py:159,211); every later frame
  * starts from its predecessor's RESULT, preserves that result's body pose with cfg->pose_preserve_weight and runs
  * followup_iters iterations (world_space.py:214).  Every frame is one k2b_fit_world_lbfgs fit; the call only queues launches
- * (no host work between the frames).
+ * (no host work between the frames) - ONE launch for the whole sequence where the fused kernel takes it (24-joint model,
+ * kinematic targets: the frame loop runs inside the persistent launch), a launch or a few per frame otherwise; same bits.
  *   j3d dev [T][K][3]; conf dev [K], or [T][K] with cfg->conf_per_frame (each frame reads its own row, as the sequence API
  *   passes `conf[idx]`); *_out dev [T][...], loss_out dev [T] (may be NULL): every frame's result / loss at the result.
  * cfg->transl_prior_weight must be 0.

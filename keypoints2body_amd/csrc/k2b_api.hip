@@ -849,7 +849,7 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
                    const float* bp_in, const float* be_in, const float* tr_in, const float* preserve,
                    const float* tr_prior, float* go_out,
                    float* bp_out, float* be_out, float* tr_out, float* loss_out, float* grad_out, void* stream,
-                   int chain_len, int chain_iters, int lb_mode = 0, const k2b::LbfgsArgs* lb_host = nullptr) {
+                   int chain_len, int chain_iters, int lb_mode = 0, const k2b::LbfgsArgs* lb_host = nullptr, int lb_chain_max_iter = 0) {
     k2b_model* model = const_cast<k2b_model*>(model_c);
     if (!model || !prior || !cfg) return fail(K2B_ERR_INVALID_ARGUMENT, "k2b_fit_world: model, prior and cfg are required");
     const int pose_dims_all = 3 * (model->J - 1);
@@ -950,7 +950,8 @@ int fit_world_impl(const k2b_model* model_c, const k2b_prior* prior, const k2b_f
     a.num_cus = device_cus();
     a.lb_mode = lb_mode;
     if (lb_host) { a.lbv = *lb_host; a.lb_loss = lb_host->loss_in; a.lb_grad = lb_host->grad_in; a.lb_history = lb_host->H; }
-    if (lb_mode != 0 && (!vsel.empty() || chain_len > 1 || !lb_host))
+    a.lb_chain_max_iter = lb_chain_max_iter;
+    if (lb_mode != 0 && (!vsel.empty() || (chain_len > 1 && lb_mode != 3) || !lb_host))
         return fail(K2B_ERR_UNSUPPORTED, "k2b_fit_world: the fused L-BFGS step needs kinematic targets and independent frames");
     if (!vsel.empty())
         return fit_world_vertex_joints(model, cfg, a, a.tr_prior, 0, vsel, vcol, (hipStream_t)stream,
@@ -1166,6 +1167,33 @@ int k2b_fit_sequence_lbfgs(const k2b_model* model_c, const k2b_prior* prior, con
 #define K2B_TRY_WS(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return cleanup(fail(K2B_ERR_HIP, "k2b_fit_sequence_lbfgs: HIP call failed")); } } while (0)
     float* pres = lbfgs_ws_assign(&w, ws, 1, P);
     k2b_fit_config fc = *cfg;
+    // The whole sequence in ONE launch where the fused kernel takes it (24-joint model, the prior over the whole pose, kinematic
+    // targets): the frame loop runs inside the persistent launch - per frame a fresh optimiser on the workgroup's idle wave, the
+    // start and the preserve pose from the predecessor's result in registers (k2b_fit.hip: chain + lb_mode 3).
+    {
+        static const int scheme_env = [] { const char* e = getenv("K2B_LBFGS_SCHEME"); return e ? atoi(e) : 0; }();
+        const int pose_dims_all = 3 * (model_c->J - 1);
+        const int prior_dims = cfg->prior_pose_dims > 0 ? cfg->prior_pose_dims : (prior->D < pose_dims_all ? prior->D : pose_dims_all);
+        bool one = scheme_env == 0 && T > 1 && model_c->fit_ok && prior->D == pose_dims_all && prior_dims == pose_dims_all &&
+                   (cfg->num_betas_prior == 0 || cfg->num_betas_prior == model_c->NB) && cfg->transl_prior_weight == 0.0f;
+        for (int k = 0; k < K && one; ++k) one = model_joint_index[k] >= 0 && model_joint_index[k] < model_c->J;
+        if (one) {
+            const int me_first = first_iters * 5 / 4, me_follow = followup_iters * 5 / 4;
+            k2b::LbfgsArgs la{};
+            la.B = 1; la.P = P; la.D = D; la.NB = NB; la.H = Hmax;
+            la.max_iter = first_iters; la.max_eval = me_first;
+            la.lr = lr; la.tol_g = tolerance_grad; la.tol_c = tolerance_change;
+            la.go = go_out; la.bp = bp_out; la.be = be_out; la.tr = tr_out;       // rows t of the outputs: frame t's point
+            la.loss_in = w.lbuf; la.grad_in = w.gbuf;
+            la.sd = reinterpret_cast<double*>(w.base); la.si = reinterpret_cast<int*>(w.base + w.off_si); la.sv = reinterpret_cast<float*>(w.base + w.off_sv);
+            K2B_TRY_WS(hipMemsetAsync(w.base, 0, w.off_sv, stream));
+            k2b_fit_config pc = fc;
+            pc.num_iters = me_first + 3;                                          // rounds + the closure at the result
+            pc.step_size = 0.0;
+            return cleanup(fit_world_impl(model_c, prior, &pc, 1, K, model_joint_index, j3d, conf, go_in, bp_in, be_in, tr_in, nullptr, nullptr,
+                                          go_out, bp_out, be_out, tr_out, loss_out, nullptr, stream_v, T, me_follow + 3, 3, &la, followup_iters));
+        }
+    }
     for (int t = 0; t < T; ++t) {
         float *go = go_out + (size_t)t * 3, *bp = bp_out + (size_t)t * D, *be = be_out + (size_t)t * NB, *tr = tr_out + (size_t)t * 3;
         const float *sgo = t ? go - 3 : go_in, *sbp = t ? bp - D : bp_in, *sbe = t ? be - NB : be_in, *str = t ? tr - 3 : tr_in;

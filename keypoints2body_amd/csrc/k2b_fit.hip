@@ -909,6 +909,13 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
         }
         for (int step = 0; step < steps; ++step) {
             const int nit = step == 0 ? a.num_iters : a.chain_iters;
+            if constexpr (MODE == MODE_SPLIT_LBFGS) {
+                if (lb_loop && a.chain_len > 1) {             // sequence chain: a fresh optimiser per frame, on the frame's own parameter row
+                    fr.restart(lb_frame * a.chain_len + step);
+                    la.max_iter = step == 0 ? a.lbv.max_iter : a.lb_chain_max_iter;
+                    la.max_eval = la.max_iter * 5 / 4;
+                }
+            }
             if (!PAIR && step > 0 && tk >= 0) {           // targets of this step's frame (sequence s, frame row s chain_len + step)
                 const size_t ft = (size_t)f[0] * a.chain_len + step;
                 const float* y = a.j3d + (ft * a.num_targets + tk) * 3;
@@ -1229,6 +1236,14 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                 if (bodyB) { pr1[0] = x1[0]; refB[0] = x1[0]; }
                 m0[0] = v0[0] = m1[0] = v1[0] = 0.f;
             }
+            if constexpr (MODE == MODE_SPLIT_LBFGS) {
+                if (lb_loop && chain && do_row && f_valid[0]) {   // the frame's start point into ITS row of the parameter arrays: the
+                    const size_t fr_row = (size_t)f[0] * a.chain_len + step;     // optimiser reads it there (phase INIT) and moves it
+                    *out_ptr_c(fr_row, pA) = x0[0];
+                    if (actB) *out_ptr_c(fr_row, pB) = x1[0];
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+            }
         K2B_FSTAMP_DECL;
         for (int it = 0; it < nit; ++it, ++git) {
             const bool last = it == nit - 1;
@@ -1278,8 +1293,14 @@ __global__ __launch_bounds__(Shape<MODE>::NWAVES * 64) void k2b_fit_world_kernel
                     if (do_row) {    // (also behind the last closure: whatever the zero-step Adam update made of a non-finite gradient, the
                                      //  result is the parked point in the parameter arrays)
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                        x0[0] = *param_ptr(f[0], pA, a.go_in, a.bp_in, a.be_in, a.tr_in);
-                        x1[0] = actB ? *param_ptr(f[0], pB, a.go_in, a.bp_in, a.be_in, a.tr_in) : 0.f;
+                        if (chain) {
+                            const size_t fr_row = (size_t)f[0] * a.chain_len + step;
+                            x0[0] = *out_ptr_c(fr_row, pA);
+                            x1[0] = actB ? *out_ptr_c(fr_row, pB) : 0.f;
+                        } else {
+                            x0[0] = *param_ptr(f[0], pA, a.go_in, a.bp_in, a.be_in, a.tr_in);
+                            x1[0] = actB ? *param_ptr(f[0], pB, a.go_in, a.bp_in, a.be_in, a.tr_in) : 0.f;
+                        }
                     }
                 }
             }
@@ -1366,8 +1387,15 @@ hipError_t launch_fit_world(const FitArgs& a_in, hipStream_t stream) {
         FitArgs a = a_in;
         int fpw = (a.num_frames + a.num_cus - 1) / a.num_cus;
         fpw = fpw < 1 ? 1 : (fpw > 4 ? 4 : fpw);
+        if (a.lb_mode == 3 && fpw > 2) fpw = 2;                  // (the optimisers sit on the idle tree waves: two sequences per workgroup)
         a.frames_per_wg = fpw;
         const dim3 grid((a.num_frames + fpw - 1) / fpw), block(MAXW * 64);
+        if (a.lb_mode == 3) {
+            if (a.num_betas <= 10) hipLaunchKernelGGL((k2b_fit_world_kernel<10, MODE_SPLIT_LBFGS>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k2b_fit_world_kernel<16, MODE_SPLIT_LBFGS>), grid, block, 0, stream, a);
+            return hipGetLastError();
+        }
+        if (a.lb_mode != 0) return hipErrorInvalidValue;
         if (a.num_betas <= 10) hipLaunchKernelGGL((k2b_fit_world_kernel<10, MODE_SPLIT>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k2b_fit_world_kernel<16, MODE_SPLIT>), grid, block, 0, stream, a);
         return hipGetLastError();

@@ -84,6 +84,7 @@ struct FitArgs {
     // writes each closure's result to lb_loss / lb_grad (= lb->loss_in / grad_in), lb_history = lb->H (host copies: no device read)
     const float *lb_loss, *lb_grad;
     int lb_history;
+    int lb_chain_max_iter;      // lb_mode 3 with chain_len > 1 (the default sequence mode in ONE launch): max_iter of the follow-up frames (lbv: the first's)
 };
 
 hipError_t launch_fit_world(const FitArgs& a, hipStream_t stream);

@@ -86,6 +86,7 @@ typedef float Vec[EPL];
 struct Frame {
     const LbfgsArgs& a;
     int f, lane, P, H;
+    int fp;                                      // row of the parameter arrays the closure evaluates (= f except in a sequence chain)
     double* sd;
     int* si;
     float* sv;
@@ -98,14 +99,14 @@ struct Frame {
     bool resident;                               // the object lives across rounds (persistent launch): LDS keeps the pairs BY RING SLOT, nothing is re-staged
     // (unbound: touches no memory - a kernel may declare the object and bind it only where an optimiser really runs)
     __device__ __forceinline__ explicit Frame(const LbfgsArgs& a_)
-        : a(a_), f(0), lane(0), P(0), H(0), sd(nullptr), si(nullptr), sv(nullptr), lds_hist(nullptr), lds_al(nullptr), lds_pairs(0), PL(0),
+        : a(a_), f(0), lane(0), P(0), H(0), fp(0), sd(nullptr), si(nullptr), sv(nullptr), lds_hist(nullptr), lds_al(nullptr), lds_pairs(0), PL(0),
           resident(false) {}
     __device__ __forceinline__ Frame(const LbfgsArgs& a_, int f_, int lane_, float* lds_hist_, double* lds_al_, int lds_pairs_) : Frame(a_) {
         bind(f_, lane_, lds_hist_, lds_al_, lds_pairs_);
     }
     // frame f_ of the batch: pointers, then the 27 scalars of its state
     __device__ __forceinline__ void bind(int f_, int lane_, float* lds_hist_, double* lds_al_, int lds_pairs_) {
-        f = f_; lane = lane_; P = a.P; H = a.H;
+        f = f_; fp = f_; lane = lane_; P = a.P; H = a.H;
         sd = a.sd + (size_t)f_ * (SD_RO + a.H); si = a.si + (size_t)f_ * SI_COUNT;
         sv = a.sv + (size_t)f_ * (size_t)(SV_HIST + 2 * a.H) * a.P;
         lds_hist = lds_hist_; lds_al = lds_al_; lds_pairs = lds_pairs_;
@@ -116,6 +117,15 @@ struct Frame {
         s.phase = si[SI_PHASE]; s.nold = si[SI_NOLD]; s.niter = si[SI_NITER]; s.evals = si[SI_EVALS]; s.ls_iter = si[SI_LS_ITER];
         s.max_ls = si[SI_MAX_LS]; s.ls_evals = si[SI_LS_EVALS]; s.first = si[SI_FIRST]; s.low = si[SI_LOW]; s.insuf = si[SI_INSUF];
         s.head = si[SI_HEAD];
+    }
+    // a fresh optimiser on the resident object (the next frame of a sequence chain): phase INIT, empty history, vectors cleared
+    __device__ __forceinline__ void restart(int param_row) {
+        fp = param_row;
+        s = Scal{};
+#pragma unroll
+        for (int w = 0; w < SV_HIST; ++w)
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) V[w][k] = 0.f;
     }
     __device__ __forceinline__ bool has(int k) const { return lane + 64 * k < P; }
     // every state vector and the new gradient: 27 independent loads (a frame in phase INIT has no vectors yet: zeros)
@@ -154,10 +164,10 @@ struct Frame {
 
     // the parameter arrays the closure reads (kernel layout [global_orient | body_pose | betas | transl])
     __device__ __forceinline__ float* eval_ptr(int e) const {
-        if (e < 3) return a.go + (size_t)f * 3 + e;
-        if (e < 3 + a.D) return a.bp + (size_t)f * a.D + (e - 3);
-        if (e < 3 + a.D + a.NB) return a.be + (size_t)f * a.NB + (e - 3 - a.D);
-        return a.tr + (size_t)f * 3 + (e - 3 - a.D - a.NB);
+        if (e < 3) return a.go + (size_t)fp * 3 + e;
+        if (e < 3 + a.D) return a.bp + (size_t)fp * a.D + (e - 3);
+        if (e < 3 + a.D + a.NB) return a.be + (size_t)fp * a.NB + (e - 3 - a.D);
+        return a.tr + (size_t)fp * 3 + (e - 3 - a.D - a.NB);
     }
     __device__ __forceinline__ double dot(const Vec& u, const Vec& v) const {
         double acc = 0.0;
