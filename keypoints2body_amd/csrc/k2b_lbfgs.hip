@@ -10,11 +10,18 @@
 //   * torch's algorithm (LBFGS.step, _strong_wolfe, _cubic_interpolate: two-loop recursion, bracket phase, zoom phase with its
 //     insufficient-progress rule, the tolerance / max_iter / max_eval exits) restated as a per-frame state machine
 //     INIT -> (BRACKET | ZOOM)* -> DONE that consumes ONE closure result per call and names the next point to evaluate;
-//   * one wavefront per frame: vectors (<= 192 parameters) three elements per lane in global memory (history: 2 H P floats),
-//     inner products reduced over the wave in double, scalars in double where torch holds Python floats;
-//   * the host only ENQUEUES a fixed number of [evaluate-only fit launch, step launch] rounds - max_eval + 2, the most any frame
-//     can need - without reading anything back: frames that finish early idle at their final point (their evaluations are
-//     ignored).  No host synchronisation, no PCIe traffic, any number of frames per launch.
+//   * one wavefront per frame (k2b_lbfgs_device.h): vectors (<= 192 parameters) three elements per lane, in registers for the
+//     whole step; state and history (2 H P floats) in global memory between steps, the history staged in LDS for the two-loop
+//     recursion; inner products reduced over the wave in double (DPP scan), scalars in double where torch holds Python floats;
+//     no FMA contraction (the code is inlined into three kernels and must round alike in each);
+//   * the host only ENQUEUES a fixed number of [closure, step] rounds - max_eval + 2, the most any frame can need - without
+//     reading anything back: frames that finish early idle at their final point.  No host synchronisation, no PCIe traffic.
+//     THREE ways the rounds reach the device, by the batch size, bit-identical (tests/test_gpu_lbfgs.py):
+//       - at most two frames per CU: ONE persistent launch of the fused fit kernel (k2b_fit.hip, lb_mode 3) - the closures are
+//         iterations of its loop, the optimiser lives on an idle wave of the workgroup with its state resident; with chain_len
+//         frames the same launch runs the whole warm-start sequence (k2b_fit_sequence_lbfgs);
+//       - at most four: one launch per round, the step as a prologue of the closure's launch (lb_mode 1 / 2);
+//       - beyond, and for the larger models: two launches per round - the closure's, and k2b_lbfgs_step_kernel below.
 //
 // CPU twin: keypoints2body_amd/core/lbfgs_batched.py (itself pinned to torch.optim.LBFGS iterate by iterate in float64,
 // tests/test_lbfgs_batched.py); tests/test_gpu_lbfgs.py compares the two on the real closure.
