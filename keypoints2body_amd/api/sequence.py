@@ -174,9 +174,11 @@ def optimize_params_sequence(joints_seq, *, init_params: Optional[BodyModelParam
     results: list[BodyModelFitResult] = []
     T = xyz.shape[0]
     est = engine.estimator
-    if (seq_cfg.use_previous_frame_init and T > 1 and frame_cfg.coordinate_mode == "world"
+    if (seq_cfg.use_previous_frame_init and T > 1
             and hasattr(est.fitter, "chain_supported") and est.fitter.chain_supported(model_indices)):
-        if prev.transl is None:
+        # world mode: the whole chain is one launch (Adam: k2b_fit_sequence, L-BFGS: k2b_fit_sequence_lbfgs); camera mode: the
+        # stages are enqueued frame by frame, the reported loss and the final forward once for all frames
+        if frame_cfg.coordinate_mode == "world" and prev.transl is None:
             prev = _with_root_aligned_transl(prev, xyz[0:1], model, frame_cfg, device)
         out, joints, verts, loss = est.fit_chain(prev, xyz, conf, model_indices)
         return _batched_results(est, out, joints, verts, loss, prev, T)

@@ -46,12 +46,18 @@ _TORSO_IDX = [JOINT_MAP[name] for name in TORSO_JOINTS]     # same indices in th
 _SQUARED_ERROR_SIGMA = 1.0e8                                # gmof(e, sigma) -> e^2 in fp32
 
 
-def guess_init_3d(model_joints, j3d, joints_category="SMPL24"):
+def guess_init_3d(model_joints, j3d, joints_category="SMPL24", torso_index: Optional[torch.Tensor] = None,
+                  torso_targets: Optional[torch.Tensor] = None):
     """Initial camera translation: mean offset of the four torso joints
-    (reference ``camera_space.py:16-41``)."""
+    (reference ``camera_space.py:16-41``).  ``torso_index`` (the four indices as a tensor on the joints' device) and
+    ``torso_targets`` (``j3d[:, torso]`` gathered before) spare the frame loop of a sequence an index upload per call; the
+    arithmetic - and so the result, bit for bit - is the same."""
     if joints_category not in ("SMPL24", "AMASS"):
         raise ValueError(f"Unknown joints category: {joints_category}")
-    return (j3d[:, _TORSO_IDX] - model_joints[:, _TORSO_IDX]).sum(dim=1) / 4.0
+    if torso_index is None:
+        return (j3d[:, _TORSO_IDX] - model_joints[:, _TORSO_IDX]).sum(dim=1) / 4.0
+    tgt = torso_targets if torso_targets is not None else j3d.index_select(1, torso_index)
+    return (tgt - model_joints.index_select(1, torso_index)).sum(dim=1) / 4.0
 
 
 class CameraSpaceFitter:
@@ -105,35 +111,71 @@ class CameraSpaceFitter:
         reported loss): ``(params dict of (B, .) tensors - ``transl`` = the camera translation -, joints, vertices,
         per-frame loss)``; ``run_forward=False`` leaves the final forward to the caller (``final_forward``), as the sharded
         sequence path wants it.  Every frame's result is that of its own single-frame ``fit_frame`` call, bit for bit."""
-        J = self.smpl.num_joints
-        go = self._dev(init_params.global_orient, 3)
-        bp = self._dev(init_params.body_pose, 3 * (J - 1))
-        be = self._dev(init_params.betas, self.smpl.num_betas)
+        go, bp, be = self._start_rows(init_params)
         j3d = torch.as_tensor(j3d, dtype=torch.float32).to(self.device)
         B = j3d.shape[0]
         if not (go.shape[0] == bp.shape[0] == be.shape[0] == B):
             raise ValueError("init_params and j3d disagree on the number of frames")
-
-        if target_model_indices is None:
-            if self.smpl_index is None:
-                raise ValueError("joints_category='GENERIC' needs target_model_indices")
-            model_idx, targets = list(self.smpl_index), j3d[:, list(self.corr_index)].contiguous()
-            stage1_idx, stage1_tgt, depth_w = _TORSO_IDX, j3d[:, _TORSO_IDX].contiguous(), 200.0
-        else:
-            model_idx = [int(i) for i in torch.as_tensor(target_model_indices).reshape(-1).tolist()]
-            targets = j3d.contiguous()
-            stage1_idx, stage1_tgt, depth_w = model_idx, targets, 100.0          # camera_space.py:199-210
+        tg = self._gather_targets(j3d, target_model_indices)
+        model_idx, targets = tg["model_idx"], tg["targets"]
         conf = None if conf_3d is None else torch.as_tensor(conf_3d, dtype=torch.float32).to(self.device).contiguous()
         if conf is not None and conf.dim() == 2 and not per_frame_conf:
             conf = conf[0].contiguous()                                          # (the reference reads row 0 only)
+        s2 = self._stages(go, bp, be, j3d, tg, conf, seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas, init_cam_t)
 
+        out = {k: s2[k] for k in ("global_orient", "body_pose", "betas", "transl")}
+        out["loss"] = self._loss_at(out, model_idx, targets, conf)
+        if not run_forward:
+            return out, None, None, out["loss"]
+        joints, verts = self.final_forward(out, want_vertices=want_vertices)
+        return out, joints, verts, out["loss"]
+
+    def _start_rows(self, init_params):
+        J = self.smpl.num_joints
+        return (self._dev(init_params.global_orient, 3), self._dev(init_params.body_pose, 3 * (J - 1)),
+                self._dev(init_params.betas, self.smpl.num_betas))
+
+    def _device_index(self, idx) -> torch.Tensor:
+        """`idx` as an int64 tensor on the device, uploaded once per index list."""
+        cache = self.__dict__.setdefault("_index_cache", {})
+        key = tuple(int(i) for i in idx)
+        if key not in cache:
+            cache[key] = torch.tensor(key, dtype=torch.int64, device=self.device)
+        return cache[key]
+
+    def _gather_targets(self, j3d, target_model_indices):
+        """Targets of both stages for however many frames `j3d` holds: stage 2 fits ``model_idx`` to ``targets``, stage 1 the
+        four torso joints (``camera_space.py:183-198``) or, with caller-chosen indices, all of them (``:199-210``)."""
+        if target_model_indices is None:
+            if self.smpl_index is None:
+                raise ValueError("joints_category='GENERIC' needs target_model_indices")
+            torso = self._device_index(_TORSO_IDX)
+            return dict(custom=False, model_idx=list(self.smpl_index),
+                        targets=j3d.index_select(1, self._device_index(self.corr_index)).contiguous(),
+                        stage1_idx=_TORSO_IDX, stage1_tgt=j3d.index_select(1, torso).contiguous(), depth_w=200.0, torso=torso)
+        model_idx = [int(i) for i in torch.as_tensor(target_model_indices).reshape(-1).tolist()]
+        targets = j3d.contiguous()
+        return dict(custom=True, model_idx=model_idx, targets=targets, stage1_idx=model_idx, stage1_tgt=targets, depth_w=100.0,
+                    torso=None)
+
+    def _stages(self, go, bp, be, j3d, tg, conf, seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas,
+                init_cam_t=None, rows: Optional[slice] = None):
+        """Initial camera translation + both stages for the frames `rows` of `j3d` / `tg` (all of them by default), started
+        from (go, bp, be) on the device: the parameters behind stage 2 (``transl`` = the camera translation).  Only launches
+        are enqueued: nothing is uploaded or read back."""
+        sl = slice(None) if rows is None else rows
+        model_idx, targets = tg["model_idx"], tg["targets"][sl]
+        stage1_idx, stage1_tgt = tg["stage1_idx"], tg["stage1_tgt"][sl]
         # initial camera translation (camera_space.py:110-134)
         if init_cam_t is None:
-            joints0 = self.smpl(global_orient=go, body_pose=bp, betas=be, return_verts=False).joints
-            if target_model_indices is None:
-                cam_t0 = guess_init_3d(joints0, j3d, self.joints_category)
+            if self.smpl.packed:
+                joints0 = self.smpl(global_orient=go, body_pose=bp, betas=be, return_verts=False).joints
             else:
-                cam_t0 = j3d[:, 0, :] - joints0[:, model_idx[0], :]
+                joints0 = self.smpl.native.lbs(go, bp, be, None, want_vertices=False)[0]
+            if not tg["custom"]:
+                cam_t0 = guess_init_3d(joints0, None, self.joints_category, torso_index=tg["torso"], torso_targets=stage1_tgt)
+            else:
+                cam_t0 = j3d[sl][:, 0, :] - joints0[:, model_idx[0], :]
         else:
             cam_t0 = torch.as_tensor(init_cam_t, dtype=torch.float32).to(self.device)
         cam_t0 = cam_t0.detach().contiguous()
@@ -145,20 +187,55 @@ class CameraSpaceFitter:
             return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, idx, tgt, cf, *cur,
                                     transl_prior_target=cam_t0)
 
-        cfg1, cfg2, fit_betas = self.stage_configs(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas, depth_w)
+        cfg1, cfg2, fit_betas = self.stage_configs(seq_ind, joint_loss_weight, pose_preserve_weight, freeze_betas, tg["depth_w"])
         start = dict(global_orient=go, body_pose=bp, betas=be, transl=cam_t0)
         if self.use_lbfgs:
-            s2 = self._two_stages_lbfgs(cfg1, cfg2, fit_betas, stage1_idx, stage1_tgt, model_idx, targets, conf, start, cam_t0)
-        else:
-            s1 = fit(cfg1, stage1_idx, stage1_tgt, None, start)
-            s2 = fit(cfg2, model_idx, targets, conf, s1)
+            return self._two_stages_lbfgs(cfg1, cfg2, fit_betas, stage1_idx, stage1_tgt, model_idx, targets, conf, start, cam_t0)
+        s1 = fit(cfg1, stage1_idx, stage1_tgt, None, start)
+        return fit(cfg2, model_idx, targets, conf, s1)
 
-        # loss at the fitted parameters: weight 600, no preserve term (camera_space.py:316-326)
+    def _loss_at(self, p, model_idx, targets, conf):
+        """Loss at the fitted parameters: weight 600, no preserve term, no depth prior (``camera_space.py:316-326``) - one
+        evaluate-only launch (one iteration with step size 0) over however many frames `p` holds."""
         cfg = native.default_fit_config()
         cfg.num_iters, cfg.step_size, cfg.joint_loss_weight = 1, 0.0, 600.0
-        final = fit(cfg, model_idx, targets, conf, s2)
-        out = {k: s2[k] for k in ("global_orient", "body_pose", "betas", "transl")}
-        out["loss"] = final["loss"]
+        cfg.conf_per_frame = int(conf is not None and conf.dim() == 2)
+        return native.fit_world(self.smpl.native, self.pose_prior.native, cfg, model_idx, targets, conf, p["global_orient"],
+                                p["body_pose"], p["betas"], p["transl"])["loss"]
+
+    def chain_supported(self, target_model_indices=None) -> bool:
+        """Any target set: the stages go through ``k2b_fit_world`` / ``k2b_fit_world_lbfgs`` frame by frame."""
+        return True
+
+    def fit_chain(self, init_params: SMPLData, j3d: torch.Tensor, conf_3d: Optional[torch.Tensor] = None,
+                  target_model_indices: Optional[torch.Tensor] = None, joint_loss_weight: float = 600.0,
+                  pose_preserve_weight: float = 5.0, freeze_betas: bool = True, want_vertices: bool = True,
+                  run_forward: bool = True):
+        """One sequence in warm-start mode (the reference's default frame loop, ``api/sequence.py:214-281`` with
+        ``use_previous_frame_init=True``, in camera mode): frame t starts from frame t-1's fitted pose and shape, its camera
+        translation from ``guess_init_3d`` at that start (``camera_space.py:110-134``; the previous translation is not used).
+
+        The two stages of a frame depend on the frame before, so they are enqueued frame by frame (nothing is read back in
+        between); what does NOT depend on the next frame leaves the loop: the loss at the fitted parameters is ONE
+        evaluate-only launch over all T frames and the final forward ONE LBS call, instead of one of each per frame.
+        Row t of every result is what the reference's loop of ``fit_frame`` calls returns for frame t, bit for bit with this
+        fitter's own ``fit_frame`` loop (``tests/test_gpu_api.py``)."""
+        j3d = torch.as_tensor(j3d, dtype=torch.float32).to(self.device)
+        T = j3d.shape[0]
+        conf = None if conf_3d is None else torch.as_tensor(conf_3d, dtype=torch.float32).to(self.device).contiguous()
+        go, bp, be = self._start_rows(init_params)
+        if not (go.shape[0] == bp.shape[0] == be.shape[0] == 1):
+            raise ValueError("fit_chain starts from ONE row of parameters")
+        tg = self._gather_targets(j3d, target_model_indices)             # both stages' targets of all T frames, gathered once
+        keys, rows = ("global_orient", "body_pose", "betas", "transl"), []
+        for t in range(T):
+            cf = None if conf is None else (conf[t] if conf.dim() == 2 else conf)
+            o = self._stages(go, bp, be, j3d, tg, cf, t, joint_loss_weight, pose_preserve_weight, freeze_betas,
+                             rows=slice(t, t + 1))
+            rows.append(o)
+            go, bp, be = o["global_orient"], o["body_pose"], o["betas"]
+        out = {k: torch.cat([r[k] for r in rows], dim=0).contiguous() for k in keys}
+        out["loss"] = self._loss_at(out, tg["model_idx"], tg["targets"], conf)
         if not run_forward:
             return out, None, None, out["loss"]
         joints, verts = self.final_forward(out, want_vertices=want_vertices)
