@@ -150,8 +150,9 @@ class CameraSpaceFitter:
             if self.smpl_index is None:
                 raise ValueError("joints_category='GENERIC' needs target_model_indices")
             torso = self._device_index(_TORSO_IDX)
+            identity = list(self.corr_index) == list(range(j3d.shape[1]))
             return dict(custom=False, model_idx=list(self.smpl_index),
-                        targets=j3d.index_select(1, self._device_index(self.corr_index)).contiguous(),
+                        targets=(j3d if identity else j3d.index_select(1, self._device_index(self.corr_index))).contiguous(),
                         stage1_idx=_TORSO_IDX, stage1_tgt=j3d.index_select(1, torso).contiguous(), depth_w=200.0, torso=torso)
         model_idx = [int(i) for i in torch.as_tensor(target_model_indices).reshape(-1).tolist()]
         targets = j3d.contiguous()

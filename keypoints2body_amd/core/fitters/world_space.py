@@ -132,8 +132,11 @@ class WorldSpaceFitter:
             if self.smpl_index is None:
                 raise ValueError("joints_category='GENERIC' needs target_model_indices")
             model_idx = list(self.smpl_index)
-            tgt = j3d[:, list(self.corr_index), :]
             conf_sel = list(self.corr_index)
+            if conf_sel == list(range(j3d.shape[1])):    # AMASS / SMPL24 inputs arrive in target order: the gather is the
+                tgt, conf_sel = j3d, None                # identity (on a device tensor it would upload its index list per call)
+            else:
+                tgt = j3d[:, conf_sel, :]
         else:
             model_idx = [int(i) for i in torch.as_tensor(target_model_indices).reshape(-1).tolist()]
             if len(model_idx) != j3d.shape[1]:
