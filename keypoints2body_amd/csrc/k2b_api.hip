@@ -69,6 +69,7 @@ struct k2b_model {
           *lbs_weights = nullptr;
     int *parents = nullptr, *extra_ids = nullptr;
     float *j_template = nullptr, *j_dirs = nullptr;          // device
+    float* j_basis_lane = nullptr;                           // device: [3][1 + NB][64 lanes] = template | directions, lane = joint (pose set-up)
     std::vector<float> h_j_template, h_j_dirs;               // host copies
     // fused-fit tables (J == 24 only)
     bool fit_ok = false;
@@ -313,6 +314,16 @@ int k2b_model_create(k2b_model** out, int32_t V, int32_t J, int32_t NB, int32_t 
         HIP_TRY(hipMemcpy(m->h_j_template.data(), m->j_template, m->h_j_template.size() * sizeof(float), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(m->h_j_dirs.data(), m->j_dirs, m->h_j_dirs.size() * sizeof(float), hipMemcpyDeviceToHost));
         HIP_TRY(hipFree(ws));
+        // the same numbers lane-major for the pose set-up kernel (lane = joint): one of its loads touches 1-2 cache lines instead
+        // of one per joint
+        std::vector<float> lane((size_t)3 * (1 + NB) * 64, 0.f);
+        for (int j = 0; j < J; ++j)
+            for (int c = 0; c < 3; ++c) {
+                lane[((size_t)c * (1 + NB)) * 64 + j] = m->h_j_template[j * 3 + c];
+                for (int k = 0; k < NB; ++k) lane[((size_t)c * (1 + NB) + 1 + k) * 64 + j] = m->h_j_dirs[((size_t)j * 3 + c) * NB + k];
+            }
+        HIP_TRY(hipMalloc((void**)&m->j_basis_lane, lane.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(m->j_basis_lane, lane.data(), lane.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
     // tables of the fused fit kernel: lanes follow the DFS pre-order of the tree, so that every
@@ -413,7 +424,7 @@ void k2b_model_destroy(k2b_model* m) {
     if (!m) return;
     (void)hipDeviceSynchronize();
     float* fl[] = {m->v_template, m->shapedirs, m->posedirs, m->j_regressor, m->lbs_weights, m->j_template,
-                   m->j_dirs, m->dt, m->dd};
+                   m->j_dirs, m->dt, m->dd, m->j_basis_lane};
     for (float* p : fl) if (p) (void)hipFree(p);
     k2b::k2b_half* hl[] = {m->mesh.pdh, m->mesh.pdl, m->extra.pdh, m->extra.pdl, m->wsXh, m->wsXl, m->mesh.w2, m->extra.w2, m->wsA2,
                            m->mesh.spd, m->mesh.sw, m->extra.spd, m->extra.sw};
@@ -1259,7 +1270,7 @@ int k2b_lbs(const k2b_model* model_c, int32_t B, const float* go, const float* b
         if (const int rc = reserve_lbs_workspace(m, bpad); rc != K2B_OK) return rc;
     }
     k2b::PoseArgs pa{};
-    pa.j_template = m->j_template; pa.j_dirs = m->j_dirs; pa.parents = m->parents;
+    pa.j_basis_lane = m->j_basis_lane; pa.parents = m->parents;
     pa.num_joints = m->J; pa.num_betas = m->NB; pa.num_out_joints = m->J + m->E;
     pa.num_frames = B; pa.frames_padded = bpad; pa.k_steps_x = m->k_steps_x;
     pa.go = go; pa.bp = bp; pa.be = be; pa.tr = tr;

@@ -142,8 +142,7 @@ __host__ __device__ inline size_t frag_elem(size_t frag, int k, int row) {
 // X = [vec(R_1..R_{J-1} - I) | beta | 1 | 1] as f16 hi/lo MFMA operands, plus the posed
 // kinematic joints (+ transl).
 struct PoseArgs {
-    const float* j_template;   // [J][3]
-    const float* j_dirs;       // [J][3][NB]
+    const float* j_basis_lane; // [3][1 + NB][64]: J_template (k' = 0) and J_dirs (k' = 1 + k) with the joint as the fastest index, zeros for lanes >= J
     const int* parents;        // [J]
     int num_joints, num_betas, num_out_joints;
     int num_frames, frames_padded;
@@ -153,6 +152,7 @@ struct PoseArgs {
     k2b_half* a2;              // group layout of the tile kernel (see TileArgs)
     int a2_stream_order;       // 1: k-groups of an entry in the stream kernel's order hi.. | PAD | lo.. | ZERO (see StreamArgs)
     float* joints_out;         // [B][num_out_joints][3] (first J rows written) or null
+    int xcd_frames;            // set by the launcher: 0 = workgroup b takes frame b; else XCD label b % 8 takes the frames [x, x + 1) * xcd_frames
 };
 hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream);
 int lbs_frames_padded(int num_frames);

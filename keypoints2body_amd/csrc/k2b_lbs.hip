@@ -38,6 +38,25 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+// Timing-only diagnostic builds (no stores / no fills / no MFMAs / L2-resident stores / s_memtime stamps) live outside this file:
+// tools/build_lbs_variants.sh compiles it with -DK2B_LBS_DIAG_HEADER=<tools/lbs_diag.h>, which redefines the hooks below.
+#ifdef K2B_LBS_DIAG_HEADER
+#include K2B_LBS_DIAG_HEADER
+#else
+#define K2B_DIAG_SKIP_FILL(lq) false              // true: this slice's fills are not issued
+#define K2B_DIAG_STORE(f, ok) ((void)0)           // may redirect the frame row / validity of a store
+#define K2B_DIAG_MFMA(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0)
+#define K2B_DIAG_STAMP_DECL ((void)0)
+#define K2B_DIAG_STAMP(slice, k) ((void)0)
+#define K2B_DIAG_TILE_DONE ((void)0)
+#define K2B_DIAG_KERNEL_END ((void)0)
+#endif
+#ifndef K2B_PSTAMP                                 // phase stamps of the pose set-up kernel (tools/dev_pose_stamps.py)
+#define K2B_PSTAMP_DECL ((void)0)
+#define K2B_PSTAMP(i) ((void)0)
+#define K2B_PSTAMP_END ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Pose set-up: one 64-lane workgroup per frame, lane j = joint j.
 // ---------------------------------------------------------------------------------------------
@@ -50,11 +69,18 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
     __shared__ float sR[kMaxJoints][9];
     __shared__ float sd[kMaxJoints][3];
     __shared__ int spar[kMaxJoints];
-    const int f = blockIdx.x;
+    // Workgroups go round-robin over the 8 XCDs, and the 16 / 32 frames that share a 256-byte group of A (a 1 KiB piece of X)
+    // write 16 bytes of it each: with consecutive frames on consecutive XCDs every L2 holds two of a line's sixteen pieces and
+    // writes them back as partial lines.  XCD label x = block % 8 therefore takes the CONTIGUOUS frames [x per, (x + 1) per),
+    // per a multiple of 32: a line is completed inside one L2.
+    const int f = a.xcd_frames ? (int)(blockIdx.x & 7) * a.xcd_frames + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (f >= a.num_frames) return;                       // (whole workgroup, before any barrier)
     const int j = threadIdx.x;
     const int J = a.num_joints, NB = a.num_betas;
     const bool act = j < J;
     const int bp = a.frames_padded;
+    K2B_PSTAMP_DECL;
+    K2B_PSTAMP(0);
 
     // Every load of this prologue is issued before the first use (fixed trip counts, predicated on k < NB): the kernel is
     // one dependent chain per frame, and a loop of NB load -> fma round trips to L2 was a third of its time.
@@ -73,9 +99,10 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float dir[NBC];
+            const float* tab = a.j_basis_lane + (size_t)c * (1 + NB) * 64 + j;     // lane-major: a load = 1-2 cache lines for the wave
 #pragma unroll
-            for (int k = 0; k < NBC; ++k) dir[k] = k < NB ? a.j_dirs[(j * 3 + c) * NB + k] : 0.f;
-            float s = a.j_template[j * 3 + c];
+            for (int k = 0; k < NBC; ++k) dir[k] = k < NB ? tab[(1 + k) * 64] : 0.f;
+            float s = tab[0];
 #pragma unroll
             for (int k = 0; k < NBC; ++k) s += dir[k] * beta[k];      // (k >= NB adds exact zeros: same sum for every capacity)
             e[c] = s;
@@ -84,11 +111,13 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         sJ[j][0] = e[0]; sJ[j][1] = e[1]; sJ[j][2] = e[2];
         spar[j] = par;
     }
+    K2B_PSTAMP(1);
     const Rodrigues rod = rodrigues_fwd(th);
     if (act) {
         for (int i = 0; i < 9; ++i) sR[j][i] = rod.R.m[i];
     }
     __syncthreads();
+    K2B_PSTAMP(2);
     if (act) {      // offset from the parent's rest joint (the parent's J(beta) comes from its own lane)
         const Vec3 Jp = par >= 0 ? Vec3{sJ[par][0], sJ[par][1], sJ[par][2]} : Vec3{0.f, 0.f, 0.f};
         const Vec3 d = Jj - Jp;
@@ -118,6 +147,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         put_x(k, x);
     }
 
+    K2B_PSTAMP(3);
     // global transform: compose towards the root
     Mat3 Rg = rod.R;
     Vec3 pg = {0.f, 0.f, 0.f};
@@ -131,6 +161,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
             Rg = mul(Ra, Rg);
         }
     }
+    K2B_PSTAMP(4);
     // A_j = [Rg | pg - Rg J_j] (k = joint; zero rows for the padded joints J .. 16 k_steps_a - 1)
     {
         const Vec3 rj = mul(Rg, Jj);
@@ -144,6 +175,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
         }
     }
     __syncthreads();
+    K2B_PSTAMP(5);
     {
         const int tiles = bp >> 5, tile = f >> 5;
         const int nx = 2 * a.k_steps_x;                    // chunks per X array
@@ -153,6 +185,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
             *reinterpret_cast<uint4*>((lo ? a.xl : a.xh) + frag_elem((size_t)ks * tiles + tile, 8 * h, f)) = v;
         }
     }
+    K2B_PSTAMP(6);
     if (a.a2) {
         // group layout of the tile kernel: [16-frame tile][entry][hi groups | lo groups | PAD | ZERO][row 16][8]; the PAD group of
         // the entries 3, 7, 11 carries the translation as three f16 terms (hi + mid + lo: 33 bits), ZERO is never written
@@ -181,6 +214,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
             *reinterpret_cast<uint4*>(base + grp * 16 * 8) = v;
         }
     }
+    K2B_PSTAMP(7);
     if (!act) return;
     if (a.joints_out) {
         float* o = a.joints_out + ((size_t)f * a.num_out_joints + j) * 3;
@@ -188,6 +222,7 @@ __global__ __launch_bounds__(64) void k2b_pose_setup_kernel(const PoseArgs a) {
                     tz = a.tr ? a.tr[(size_t)f * 3 + 2] : 0.f;
         o[0] = pg.x + tx; o[1] = pg.y + ty; o[2] = pg.z + tz;
     }
+    K2B_PSTAMP_END;
 }
 
 constexpr int kFragHalfs = 512;      // one piece = 64 lanes x 8 halfs = 1 KiB
@@ -213,19 +248,6 @@ constexpr int kFragHalfs = 512;      // one piece = 64 lanes x 8 halfs = 1 KiB
 // ---------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int kTileSlotBytes = 64 * 1024;
-// Timing-only diagnostic builds (no stores / no fills / no MFMAs / L2-resident stores / s_memtime stamps) live outside this file:
-// tools/build_lbs_variants.sh compiles it with -DK2B_LBS_DIAG_HEADER=<tools/lbs_diag.h>, which redefines the hooks below.
-#ifdef K2B_LBS_DIAG_HEADER
-#include K2B_LBS_DIAG_HEADER
-#else
-#define K2B_DIAG_SKIP_FILL(lq) false              // true: this slice's fills are not issued
-#define K2B_DIAG_STORE(f, ok) ((void)0)           // may redirect the frame row / validity of a store
-#define K2B_DIAG_MFMA(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0)
-#define K2B_DIAG_STAMP_DECL ((void)0)
-#define K2B_DIAG_STAMP(slice, k) ((void)0)
-#define K2B_DIAG_TILE_DONE ((void)0)
-#define K2B_DIAG_KERNEL_END ((void)0)
-#endif
 #ifndef K2B_TILE_AHEAD
 #define K2B_TILE_AHEAD(NKT) ((NKT) <= 3)
 #endif
@@ -616,11 +638,16 @@ __global__ void k2b_gather_joints_kernel(const float* __restrict__ verts, const 
 
 int lbs_frames_padded(int num_frames) { return (num_frames + 31) / 32 * 32; }
 
-hipError_t launch_pose_setup(const PoseArgs& a, hipStream_t stream) {
-    if (a.num_frames <= 0) return hipSuccess;
-    if (a.k_steps_x > kMaxXSteps || a.num_joints > kMaxJoints || a.num_betas > kMaxShape) return hipErrorInvalidValue;
-    const int GA = tile_groups_a(a.num_joints);
-    const dim3 grid(a.num_frames), block(64);
+hipError_t launch_pose_setup(const PoseArgs& a_in, hipStream_t stream) {
+    if (a_in.num_frames <= 0) return hipSuccess;
+    if (a_in.k_steps_x > kMaxXSteps || a_in.num_joints > kMaxJoints || a_in.num_betas > kMaxShape) return hipErrorInvalidValue;
+    const int GA = tile_groups_a(a_in.num_joints);
+    PoseArgs a = a_in;
+#ifndef K2B_POSE_XCD
+#define K2B_POSE_XCD 1
+#endif
+    a.xcd_frames = (K2B_POSE_XCD && a.num_frames > 256) ? (a.num_frames + 255) / 256 * 32 : 0;
+    const dim3 grid(a.xcd_frames ? 8 * a.xcd_frames : a.num_frames), block(64);
 #define K2B_POSE(NBC_, GA_) hipLaunchKernelGGL((k2b_pose_setup_kernel<NBC_, GA_>), grid, block, 0, stream, a)
     if (GA == 3) { if (a.num_betas <= 10) K2B_POSE(10, 3); else if (a.num_betas <= 16) K2B_POSE(16, 3); else K2B_POSE(32, 3); }
     else if (GA == 7) { if (a.num_betas <= 10) K2B_POSE(10, 7); else if (a.num_betas <= 20) K2B_POSE(20, 7); else K2B_POSE(32, 7); }

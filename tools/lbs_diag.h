@@ -102,3 +102,20 @@
 #define K2B_SXDIAG_TILE ((void)0)
 #define K2B_SXDIAG_STORES 0
 #endif
+
+// ---- pose set-up kernel (k2b_pose_setup_kernel) ---------------------------------------------------------------------------------
+//   K2B_POSE_STAMPS 1: s_memtime at nine points of every frame's workgroup (0 start, 1 parameters loaded + J(beta), 2 Rodrigues +
+//   barrier, 3 offsets + barrier + X staged, 4 chain composed, 5 A staged + barrier, 6 X stored, 7 A stored, 8 all stores
+//   acknowledged); lane 0 writes the differences to the start as floats over the frame's first three output joints
+//   (tools/dev_pose_stamps.py reads them; the joints of such a build are wrong on purpose)
+#if K2B_POSE_STAMPS
+#define K2B_PSTAMP_DECL unsigned long long pst[10]
+#define K2B_PSTAMP(i) pst[i] = __builtin_amdgcn_s_memtime()
+#define K2B_PSTAMP_END                                                                         \
+    do {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        K2B_PSTAMP(8);                                                                         \
+        if (j == 0 && a.joints_out)                                                            \
+            for (int i = 0; i < 9; ++i) a.joints_out[(size_t)f * a.num_out_joints * 3 + i] = (float)(pst[i] - pst[0]); \
+    } while (0)
+#endif
