@@ -19,7 +19,7 @@ j3d = j[:, :22].contiguous()
 z = lambda *s: torch.zeros(*s, device='cuda')
 j0, _ = m.lbs(z(B, 3), z(B, 69), z(B, 10), None, want_vertices=False)
 tr0 = (j3d[:, 0] - j0[:, 0]).contiguous()
-cfg = native.default_fit_config(); cfg.num_iters = 100
+cfg = native.default_fit_config(); cfg.num_iters = int(os.environ.get('K2B_DEV_ITERS', '100'))
 if len(sys.argv) > 5: cfg.debug_launch_shape = int(sys.argv[5])
 if wpp is not None: cfg.pose_prior_weight = wpp
 run = lambda: native.fit_world(m, pr, cfg, list(range(22)), j3d, None, z(B, 3), z(B, 69), z(B, 10), tr0)
